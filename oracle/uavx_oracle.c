@@ -1,0 +1,498 @@
+/* uavx_oracle.c — CPU restatement of the reference step/reset path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Every function cites the reference lines it follows (MUW / AG / UW, see uavx_oracle.h).  The
+ * arithmetic reproduces what numpy 2.2.6 (NEP 50 promotion) + CPython's math module (glibc libm)
+ * evaluate for those lines; build with -ffp-contract=off so no FMA is formed except where numpy
+ * itself uses one (the float64 2-element dot inside np.linalg.norm, see nrm64()).
+ * Pinned by tests/test_oracle_golden.py against fixtures generated from the reference.
+ */
+#include "uavx_oracle.h"
+
+#include <math.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define HARD_COLLISION_RADIUS 0.5 /* MUW:8 */
+#define MAXN 64
+
+/* ------------------------------------------------------------------------------------------------
+ * numpy building blocks
+ * ---------------------------------------------------------------------------------------------- */
+
+/* np.linalg.norm of a 2-element float64 vector = sqrt(dot(x,x)); the OpenBLAS ddot numpy 2.2.6
+ * ships evaluates the 2-term dot as fma(y,y,x*x) (checked against numpy on 20 000 samples, 0
+ * mismatches; the plain x*x+y*y form differs in ~8 % of samples by 1 ulp). */
+static inline double nrm64(double x, double y) { return sqrt(fma(y, y, x * x)); }
+
+/* np.linalg.norm of a 2-element float32 vector: float32 mul, mul, add, sqrtf, no FMA
+ * (200 000-sample check in SURVEY.md §0.5). */
+static inline float nrm32(float x, float y) {
+    float a = x * x;
+    float b = y * y;
+    float s = a + b;
+    return sqrtf(s);
+}
+
+/* np.clip(x, lo, hi) == minimum(maximum(x, lo), hi) */
+static inline double clipd(double x, double lo, double hi) {
+    double m = (x < lo) ? lo : x; /* NaN stays NaN like np.maximum */
+    if (x != x) m = x;
+    double r = (m > hi) ? hi : m;
+    if (m != m) r = m;
+    return r;
+}
+
+/* atan2(sin d, cos d): the reference's angle wrap (MUW:71,80,84,90,94,186; UW:93,156) */
+static inline double wrap_angle(double d) { return atan2(sin(d), cos(d)); }
+
+/* ‖a − b‖ as the reference's position dtype evaluates it (float32 arrays unless circular). */
+static inline double pos_dist(int f64pos, double ax, double ay, double bx, double by) {
+    if (f64pos) return nrm64(ax - bx, ay - by);
+    float dx = (float)ax - (float)bx;
+    float dy = (float)ay - (float)by;
+    return (double)nrm32(dx, dy);
+}
+/* component of (a − b) as a Python float handed to math.atan2 */
+static inline double pos_sub(int f64pos, double a, double b) {
+    if (f64pos) return a - b;
+    return (double)((float)a - (float)b);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RNGs
+ * ---------------------------------------------------------------------------------------------- */
+void uavo_mt_seed(uavo_mt *g, uint32_t seed) { /* numpy legacy np.random.seed(int) == init_genrand */
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; i++)
+        g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+static uint32_t mt_next(uavo_mt *g) {
+    if (g->idx >= 624) {
+        uint32_t *mt = g->mt;
+        for (int k = 0; k < 624; k++) {
+            uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            uint32_t v = mt[(k + 397) % 624] ^ (y >> 1);
+            if (y & 1u) v ^= 0x9908b0dfu;
+            mt[k] = v;
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+static inline double bits53(uint32_t a, uint32_t b) { /* numpy random_sample: 53-bit double */
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+double uavo_mt_double(uavo_mt *g) {
+    uint32_t a = mt_next(g), b = mt_next(g);
+    return bits53(a, b);
+}
+
+void uavo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* A draw source yields pairs of U[0,1) doubles in the order np.random.uniform(lo,hi,(2,)) would. */
+typedef struct {
+    uavo_mt *mt;          /* MT path */
+    uint32_t key[2];      /* Philox path */
+    uint32_t ctr_env[2], episode, draw;
+} draw_src;
+
+static void draw_pair(draw_src *s, double u[2]) {
+    if (s->mt) {
+        u[0] = uavo_mt_double(s->mt);
+        u[1] = uavo_mt_double(s->mt);
+    } else {
+        uint32_t ctr[4] = {s->ctr_env[0], s->ctr_env[1], s->draw++, s->episode}, o[4];
+        uavo_philox4x32(ctr, s->key, o);
+        u[0] = bits53(o[0], o[1]);
+        u[1] = bits53(o[2], o[3]);
+    }
+}
+/* np.random.uniform(low, high, (2,)).astype(np.float32): low + (high-low)*random_sample, then cast */
+static void draw_point32(draw_src *s, double lox, double loy, double hix, double hiy, double p[2]) {
+    double u[2];
+    draw_pair(s, u);
+    p[0] = (double)(float)(lox + (hix - lox) * u[0]);
+    p[1] = (double)(float)(loy + (hiy - loy) * u[1]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MultiUAVWorld2D
+ * ---------------------------------------------------------------------------------------------- */
+
+/* AG:44-64 restricted to what the callers use (MUW:75-95,198-199): the (up to) two nearest other
+ * agents strictly within d_sense, ascending by distance, ties -> lower index (argsort on <16
+ * elements is a stable insertion sort).  px/py are the positions to use for each agent. */
+static int nearest_two(int n, int self, int f64pos, const double *px, const double *py,
+                       double d_sense, int idx[2], double dist[2]) {
+    int cnt = 0;
+    double lim = f64pos ? d_sense : (double)(float)d_sense; /* f32 < python scalar -> f32 compare */
+    for (int j = 0; j < n; j++) {
+        if (j == self) continue;
+        double d = pos_dist(f64pos, px[j], py[j], px[self], py[self]); /* AG:51 */
+        if (!(d < lim)) continue;                                        /* AG:52 */
+        if (cnt == 0) {
+            idx[0] = j; dist[0] = d; cnt = 1;
+        } else if (d < dist[0]) {
+            idx[1] = idx[0]; dist[1] = dist[0];
+            idx[0] = j; dist[0] = d; cnt = 2;
+        } else if (cnt == 1 || d < dist[1]) {
+            idx[1] = j; dist[1] = d; cnt = 2;
+        }
+    }
+    return cnt;
+}
+
+/* MUW:60-109 for agent i of env e. */
+static void observe_agent(const uavo_config *cfg, const uavo_state *st, int64_t e, int i, double *o) {
+    const int n = st->num_agents;
+    const int f64pos = st->f64pos[e];
+    const double *loc = st->loc + e * n * 2, *vel = st->vel + e * n * 2, *tgt = st->tgt + e * n * 2;
+    double px[MAXN], py[MAXN];
+    for (int j = 0; j < n; j++) { px[j] = loc[2 * j]; py[j] = loc[2 * j + 1]; }
+
+    const double vx = vel[2 * i], vy = vel[2 * i + 1];
+    o[0] = nrm64(vx, vy) / nrm64(cfg->max_speed, cfg->max_speed);                 /* MUW:62 */
+    const double theta = atan2(vy, vx);                                             /* MUW:63 */
+    o[1] = theta / M_PI;                                                            /* MUW:64 */
+    const double rtd = pos_dist(f64pos, tgt[2 * i], tgt[2 * i + 1], px[i], py[i]);  /* MUW:67 */
+    o[2] = rtd / nrm64(cfg->x_size, cfg->y_size);                                   /* MUW:68,17 */
+    const double rtt = atan2(pos_sub(f64pos, tgt[2 * i + 1], py[i]),
+                             pos_sub(f64pos, tgt[2 * i], px[i]));                   /* MUW:69 */
+    o[3] = wrap_angle(rtt - theta) / M_PI;                                          /* MUW:70-72 */
+
+    int idx[2]; double dist[2];
+    const int cnt = nearest_two(n, i, f64pos, px, py, cfg->d_sense, idx, dist);     /* MUW:75 */
+    for (int k = 0; k < 2; k++) {
+        double nd, rel_theta, dir;
+        if (cnt > k) {
+            const int j = idx[k];
+            /* MUW:77/87: float32 norm / python scalar d_sense -> float32 division */
+            nd = f64pos ? dist[k] / cfg->d_sense : (double)((float)dist[k] / (float)cfg->d_sense);
+            rel_theta = atan2(pos_sub(f64pos, py[j], py[i]), pos_sub(f64pos, px[j], px[i])); /* MUW:78/88 */
+            dir = atan2(vel[2 * j + 1], vel[2 * j]);                                /* MUW:82/92 */
+        } else {
+            nd = 1.0;
+            rel_theta = M_PI + theta;
+            dir = theta;
+        }
+        o[4 + 3 * k] = nd;
+        o[5 + 3 * k] = wrap_angle(rel_theta - theta) / M_PI;                        /* MUW:79-81 */
+        o[6 + 3 * k] = wrap_angle(dir - theta) / M_PI;                              /* MUW:83-85 */
+    }
+}
+
+static void observe_env(const uavo_config *cfg, const uavo_state *st, int64_t e, double *obs) {
+    for (int i = 0; i < st->num_agents; i++)
+        observe_agent(cfg, st, e, i, obs + (e * st->num_agents + i) * UAVO_OBS_DIM);
+}
+
+void uavo_observe(const uavo_config *cfg, const uavo_state *st, double *obs, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) observe_env(cfg, st, e, obs);
+}
+
+/* MUW:116-168 (state part of reset; observations are produced by uavo_observe). */
+static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_src *src, int circular) {
+    const int n = st->num_agents;
+    double *loc = st->loc + e * n * 2, *vel = st->vel + e * n * 2, *tgt = st->tgt + e * n * 2;
+    double *init_d = st->init_d + e * n, *prev_d = st->prev_d + e * n;
+    uint8_t *flags = st->flags + e * n;
+    const double lox = -cfg->x_size / 2.0, loy = -cfg->y_size / 2.0;   /* MUW:19 */
+    const double hix = cfg->x_size / 2.0, hiy = cfg->y_size / 2.0;     /* MUW:20 */
+    const float two_r = (float)(2 * cfg->collider_radius);             /* f32 <= python float */
+
+    for (int i = 0; i < n; i++) { vel[2 * i] = vel[2 * i + 1] = 0.0; flags[i] = 0; } /* MUW:118-123 */
+    st->f64pos[e] = 0;
+
+    draw_point32(src, lox, loy, hix, hiy, loc);                        /* MUW:126 */
+    for (int i = 1; i < n; i++) {                                      /* MUW:127-137 */
+        int replicated = 1;
+        while (replicated) {
+            draw_point32(src, lox, loy, hix, hiy, loc + 2 * i);
+            replicated = 0;
+            for (int j = 0; j < i; j++) {
+                if ((float)pos_dist(0, loc[2 * j], loc[2 * j + 1], loc[2 * i], loc[2 * i + 1]) <= two_r) {
+                    replicated = 1;
+                    break;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; i++) {                                      /* MUW:140-155 */
+        int replicated = 1;
+        while (replicated) {
+            draw_point32(src, lox, loy, hix, hiy, tgt + 2 * i);
+            replicated = 0;
+            if ((float)pos_dist(0, tgt[2 * i], tgt[2 * i + 1], loc[2 * i], loc[2 * i + 1]) <= two_r)
+                replicated = 1;
+            for (int j = 0; j < i; j++) {
+                if ((float)pos_dist(0, tgt[2 * j], tgt[2 * j + 1], tgt[2 * i], tgt[2 * i + 1]) <= two_r) {
+                    replicated = 1;
+                    break;
+                }
+            }
+        }
+        init_d[i] = pos_dist(0, tgt[2 * i], tgt[2 * i + 1], loc[2 * i], loc[2 * i + 1]);
+        prev_d[i] = init_d[i];
+    }
+    if (circular) {                                                    /* MUW:157-163 */
+        st->f64pos[e] = 1;
+        for (int i = 0; i < n; i++) {
+            double theta = 2 * i * M_PI / n;
+            loc[2 * i] = 20.0 * 1.0 * cos(theta);
+            loc[2 * i + 1] = 20.0 * 1.0 * sin(theta);
+            tgt[2 * i] = 23.0 * 1.0 * cos(theta + M_PI);
+            tgt[2 * i + 1] = 23.0 * 1.0 * sin(theta + M_PI);
+            init_d[i] = pos_dist(1, tgt[2 * i], tgt[2 * i + 1], loc[2 * i], loc[2 * i + 1]);
+            prev_d[i] = init_d[i];
+        }
+    }
+    uint32_t *c = st->counters + e * 4;
+    c[0] = 0; c[1] = 0; c[2] = 0;                                      /* MUW:166-168 */
+}
+
+void uavo_reset_mt(const uavo_config *cfg, uavo_state *st, int64_t env, uavo_mt *g, int circular) {
+    draw_src s;
+    memset(&s, 0, sizeof s);
+    s.mt = g;
+    reset_env(cfg, st, env, &s, circular);
+}
+
+void uavo_reset_philox(const uavo_config *cfg, uavo_state *st, const uint8_t *mask, uint64_t seed,
+                       int64_t env_offset, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) {
+        if (mask && !mask[e]) continue;
+        draw_src s;
+        memset(&s, 0, sizeof s);
+        uint64_t ge = (uint64_t)(env_offset + e);
+        s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
+        s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
+        s.episode = st->counters[e * 4 + 3];
+        reset_env(cfg, st, e, &s, 0);
+        st->counters[e * 4 + 3] += 1; /* next reset of this env draws a fresh layout */
+    }
+}
+
+/* MUW:177-241 for one env. */
+static void step_env(const uavo_config *cfg, uavo_state *st, int64_t e, const double *actions,
+                     int evaluate, double *obs, double *reward, uint8_t *done_out) {
+    const int n = st->num_agents;
+    const int f64pos = st->f64pos[e];
+    double *loc = st->loc + e * n * 2, *vel = st->vel + e * n * 2, *tgt = st->tgt + e * n * 2;
+    double *init_d = st->init_d + e * n, *prev_d = st->prev_d + e * n;
+    uint8_t *flags = st->flags + e * n;
+    uint32_t *cnt = st->counters + e * 4;
+    const double tau = cfg->tau, amax = cfg->max_acceleration, vmax = cfg->max_speed;
+    const double two_r = f64pos ? 2 * cfg->collider_radius : (double)(float)(2 * cfg->collider_radius);
+    const double two_hard = 2 * HARD_COLLISION_RADIUS;
+    const double lox = -cfg->x_size / 2.0, loy = -cfg->y_size / 2.0;
+    const double hix = cfg->x_size / 2.0, hiy = cfg->y_size / 2.0;
+    double px[MAXN], py[MAXN];
+    for (int j = 0; j < n; j++) { px[j] = loc[2 * j]; py[j] = loc[2 * j + 1]; }
+
+    for (int i = 0; i < n; i++) {                                       /* MUW:181 */
+        const double *a = actions + (e * n + i) * 2;
+        double pd, d;
+        const int was_done = (flags[i] & UAVO_FLAG_DONE) != 0;
+        /* ---- UAVAgent.step, AG:23-36 ---- */
+        if (was_done) {
+            pd = 0.0; d = 0.0;                                          /* AG:24-25 */
+        } else {
+            for (int k = 0; k < 2; k++) {
+                double dv = clipd((a[k] - vel[2 * i + k]) / tau, -amax, amax);       /* AG:26 */
+                vel[2 * i + k] = clipd(vel[2 * i + k] + dv * tau, -vmax, vmax);     /* AG:27 */
+                double dx = vel[2 * i + k] * tau;                                   /* AG:28 */
+                double nl = loc[2 * i + k] + dx;       /* AG:29: float32 array += float64 array */
+                loc[2 * i + k] = f64pos ? nl : (double)(float)nl;
+            }
+            px[i] = loc[2 * i]; py[i] = loc[2 * i + 1];
+            pd = prev_d[i];                                                          /* AG:32 */
+            d = pos_dist(f64pos, tgt[2 * i], tgt[2 * i + 1], px[i], py[i]);          /* AG:33 */
+            prev_d[i] = d;                                                           /* AG:34 */
+        }
+        /* ---- reward shaping, MUW:183-195 ---- */
+        const double max_speed = nrm64(vmax, vmax);                                  /* MUW:183 */
+        double dth = atan2(pos_sub(f64pos, tgt[2 * i + 1], py[i]), pos_sub(f64pos, tgt[2 * i], px[i]))
+                     - atan2(vel[2 * i + 1], vel[2 * i]);                            /* MUW:184-185 */
+        dth = wrap_angle(dth);                                                       /* MUW:186 */
+        const double q = max_speed / init_d[i];
+        double r = 0.0 - 0.01 * ((1.0 < q) ? 1.0 : q);                               /* MUW:188-189 */
+        double prog; /* prev_distance - distance: float32 - float32 unless circular / done */
+        if (was_done) prog = 0.0;
+        else if (f64pos) prog = pd - d;
+        else prog = (double)((float)pd - (float)d);
+        r += 50.0 * (prog / max_speed);                                              /* MUW:190 */
+        double frac; /* distance/(1.5*init_distance): float32 chain under NEP 50 unless circular */
+        if (f64pos) frac = d / (1.5 * init_d[i]);
+        else frac = (double)((float)d / (1.5f * (float)init_d[i]));
+        if (r > 0) r *= f64pos ? (1 - frac) : (double)(1.0f - (float)frac);          /* MUW:191-192 */
+        else r *= f64pos ? (1 + frac) : (double)(1.0f + (float)frac);                /* MUW:193-194 */
+        r -= 0.01 * fabs(dth);                                                       /* MUW:195 */
+
+        /* ---- collisions with the <=2 nearest in-range agents, MUW:197-210 ---- */
+        int collision = 0;
+        int idx[2]; double dist[2];
+        const int nn = nearest_two(n, i, f64pos, px, py, cfg->d_sense, idx, dist);   /* MUW:198 */
+        for (int k = 0; k < nn; k++) {                                               /* MUW:199 */
+            if (dist[k] <= two_r) { r = -2.0; collision = 1; }                       /* MUW:203-205 */
+            if (dist[k] <= two_hard) {                                               /* MUW:207 */
+                if (!(flags[i] & UAVO_FLAG_DONE) && !(flags[i] & UAVO_FLAG_COLLIDED)) {
+                    cnt[2] += 1;                                                     /* MUW:209 */
+                    flags[i] |= UAVO_FLAG_COLLIDED;                                  /* MUW:210 */
+                }
+            }
+        }
+        /* ---- termination, MUW:213-227 ---- */
+        const int oob = !(px[i] >= lox && px[i] <= hix && py[i] >= loy && py[i] <= hiy); /* MUW:213,224 */
+        const double speed = nrm64(vel[2 * i], vel[2 * i + 1]);                      /* MUW:214 */
+        int dn;
+        if (d < 0.5 && !collision && speed < 0.2) {                                  /* MUW:218 */
+            dn = 1;
+            if (!(flags[i] & UAVO_FLAG_DONE)) cnt[1] += 1;                           /* MUW:220-221 */
+            /* UAVAgent.finish, AG:38-42 */
+            flags[i] |= UAVO_FLAG_DONE;
+            double nv = nrm64(vel[2 * i], vel[2 * i + 1]);
+            double fx = vel[2 * i] / nv * 0.001, fy = vel[2 * i + 1] / nv * 0.001;
+            if (fx != fx || fy != fy) { fx = 0.0; fy = 0.0; }
+            vel[2 * i] = fx; vel[2 * i + 1] = fy;
+            r += 10;                                                                 /* MUW:223 */
+        } else if (oob) {
+            dn = evaluate ? 0 : 1;                                                   /* MUW:224-225 */
+        } else {
+            dn = 0;
+        }
+        prev_d[i] = d;                                                               /* MUW:229 */
+        reward[e * n + i] = r;
+        done_out[e * n + i] = (uint8_t)dn;
+    }
+    observe_env(cfg, st, e, obs);                                                    /* MUW:233-235 */
+    cnt[0] += 1;                                                                     /* MUW:238 */
+}
+
+void uavo_step(const uavo_config *cfg, uavo_state *st, const double *actions, int evaluate,
+               double *obs, double *reward, uint8_t *done, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) step_env(cfg, st, e, actions, evaluate, obs, reward, done);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * UAVWorld2D
+ * ---------------------------------------------------------------------------------------------- */
+static void uw_observe_env(const uavo_uw_config *cfg, const uavo_uw_state *st, int64_t e, double *o) {
+    const double vx = st->vel[2 * e], vy = st->vel[2 * e + 1];
+    /* UW:88: after reset the velocity is a float32 array (UW:122) -> float32 norm */
+    const double sp = st->vel_f32[e] ? (double)nrm32((float)vx, (float)vy) : nrm64(vx, vy);
+    o[0] = sp / cfg->max_speed;                                                      /* UW:88 */
+    const double theta = atan2(vy, vx);                                              /* UW:89 */
+    o[1] = theta / M_PI;                                                             /* UW:90 */
+    const double rtt = atan2(pos_sub(0, st->tgt[2 * e + 1], st->loc[2 * e + 1]),
+                             pos_sub(0, st->tgt[2 * e], st->loc[2 * e]));            /* UW:91 */
+    o[3] = wrap_angle(rtt - theta) / M_PI;                                           /* UW:92-94 */
+    const double rtd = pos_dist(0, st->tgt[2 * e], st->tgt[2 * e + 1], st->loc[2 * e], st->loc[2 * e + 1]);
+    o[2] = rtd / nrm64(cfg->x_size, cfg->y_size);                                    /* UW:96-97,17 */
+}
+
+void uavo_uw_observe(const uavo_uw_config *cfg, const uavo_uw_state *st, double *obs, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) uw_observe_env(cfg, st, e, obs + e * UAVO_UW_OBS_DIM);
+}
+
+static void uw_reset_env(const uavo_uw_config *cfg, uavo_uw_state *st, int64_t e, draw_src *s) {
+    const double lox = -cfg->x_size / 2.0, loy = -cfg->y_size / 2.0, hix = cfg->x_size / 2.0, hiy = cfg->y_size / 2.0;
+    draw_point32(s, lox, loy, hix, hiy, st->loc + 2 * e);                            /* UW:121 */
+    draw_point32(s, -cfg->max_speed, -cfg->max_speed, cfg->max_speed, cfg->max_speed, st->vel + 2 * e); /* UW:122 */
+    st->vel_f32[e] = 1;
+    draw_point32(s, lox, loy, hix, hiy, st->tgt + 2 * e);                            /* UW:126 */
+    st->init_d[e] = pos_dist(0, st->tgt[2 * e], st->tgt[2 * e + 1], st->loc[2 * e], st->loc[2 * e + 1]); /* UW:129 */
+    st->prev_d[e] = st->init_d[e];                                                   /* UW:130 */
+    st->steps[e] = 0;                                                                /* UW:131 */
+}
+
+void uavo_uw_reset_mt(const uavo_uw_config *cfg, uavo_uw_state *st, int64_t env, uavo_mt *g) {
+    draw_src s;
+    memset(&s, 0, sizeof s);
+    s.mt = g;
+    uw_reset_env(cfg, st, env, &s);
+}
+
+void uavo_uw_reset_philox(const uavo_uw_config *cfg, uavo_uw_state *st, const uint8_t *mask,
+                          uint64_t seed, int64_t env_offset, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) {
+        if (mask && !mask[e]) continue;
+        draw_src s;
+        memset(&s, 0, sizeof s);
+        uint64_t ge = (uint64_t)(env_offset + e);
+        s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
+        s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
+        s.episode = st->episode[e];
+        uw_reset_env(cfg, st, e, &s);
+        st->episode[e] += 1;
+    }
+}
+
+static void uw_step_env(const uavo_uw_config *cfg, uavo_uw_state *st, int64_t e, const double *actions,
+                        int action_is_f32, double *obs, double *reward, uint8_t *done, double *info) {
+    const double tau = cfg->tau, amax = cfg->max_acceleration, vmax = cfg->max_speed;
+    double *loc = st->loc + 2 * e, *vel = st->vel + 2 * e, *tgt = st->tgt + 2 * e;
+    const double *a = actions + 2 * e;
+    for (int k = 0; k < 2; k++) {
+        double qv;
+        if (st->vel_f32[e] && action_is_f32)         /* UW:142: f32 array / python float -> f32 */
+            qv = (double)(((float)a[k] - (float)vel[k]) / (float)tau);
+        else
+            qv = (a[k] - vel[k]) / tau;
+        double dv = clipd(qv, -amax, amax);                                          /* UW:142 */
+        vel[k] = clipd(vel[k] + dv * tau, -vmax, vmax);                              /* UW:144 */
+        loc[k] = (double)(float)(loc[k] + vel[k] * tau);                             /* UW:145-146 */
+    }
+    st->vel_f32[e] = 0;                                                              /* UW:147 */
+    const double lox = -cfg->x_size / 2.0, loy = -cfg->y_size / 2.0, hix = cfg->x_size / 2.0, hiy = cfg->y_size / 2.0;
+    const int oob = !(loc[0] >= lox && loc[0] <= hix && loc[1] >= loy && loc[1] <= hiy); /* UW:149,162 */
+    const float d = (float)pos_dist(0, tgt[0], tgt[1], loc[0], loc[1]);              /* UW:150 */
+    float r = 0.0f - 1.0f / (float)st->init_d[e];                                    /* UW:152-153 */
+    r = r + 10.0f * ((float)st->prev_d[e] - d);                                      /* UW:154 */
+    double dth = atan2(pos_sub(0, tgt[1], loc[1]), pos_sub(0, tgt[0], loc[0])) - atan2(vel[1], vel[0]); /* UW:155 */
+    dth = wrap_angle(dth);                                                           /* UW:156 */
+    r = r - (float)(0.1 * fabs(dth));                                                /* UW:157 */
+    int dn;
+    if (d < 0.5f) { dn = 1; r = r + 1000.0f; }                                       /* UW:159-161 */
+    else if (oob) dn = 1;                                                            /* UW:162-163 */
+    else dn = 0;
+    uw_observe_env(cfg, st, e, obs + e * UAVO_UW_OBS_DIM);                           /* UW:168 */
+    info[e] = (double)d;                                                             /* UW:169,114-117 */
+    st->steps[e] += 1;                                                               /* UW:170 */
+    st->prev_d[e] = (double)d;                                                       /* UW:172 */
+    reward[e] = (double)r;
+    done[e] = (uint8_t)dn;
+}
+
+void uavo_uw_step(const uavo_uw_config *cfg, uavo_uw_state *st, const double *actions,
+                  int action_is_f32, double *obs, double *reward, uint8_t *done,
+                  double *info_distance, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++)
+        uw_step_env(cfg, st, e, actions, action_is_f32, obs, reward, done, info_distance);
+}

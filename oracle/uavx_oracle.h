@@ -1,0 +1,110 @@
+/* uavx_oracle.h — CPU restatement (TEST INFRASTRUCTURE ONLY) of the reference env step/reset path.
+ *
+ * This is the parity oracle: a scalar C restatement of
+ *   MUW = /root/reference/gym_uav_collision_avoidance/envs/multi_uav_world_2d.py
+ *   AG  = /root/reference/gym_uav_collision_avoidance/envs/uav_agent.py
+ *   UW  = /root/reference/gym_uav_collision_avoidance/envs/uav_world_2d.py
+ * following the reference's op order and dtypes as evaluated by numpy 2.2.6 (NEP 50) + glibc libm.
+ * It is pinned against fixtures generated from the reference itself (tests/golden/make_golden.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (gym_uav_collision_avoidance_amd) never links, imports or falls back to it.
+ */
+#ifndef UAVX_ORACLE_H
+#define UAVX_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVO_OBS_DIM 10
+#define UAVO_UW_OBS_DIM 4
+#define UAVO_FLAG_DONE 1u
+#define UAVO_FLAG_COLLIDED 2u
+
+/* MultiUAVWorld2D ctor arguments (MUW:13) + tau (MUW:26). */
+typedef struct {
+    double x_size, y_size;
+    double max_speed, max_acceleration;
+    double collider_radius, d_sense;
+    double tau;
+    int32_t num_agents;
+    int32_t _pad;
+} uavo_config;
+
+/* State of E independent worlds, N agents each.  Positions are held as doubles; when f64pos[e]==0
+ * (the normal case, MUW:126,131,144 astype(float32)) every value is float32-representable and all
+ * position arithmetic is done in float32 exactly like numpy does; when f64pos[e]==1 (after
+ * reset(circular=True), MUW:157-163) arithmetic is float64.  Index = (e*N + i)*2 + axis. */
+typedef struct {
+    int64_t num_envs;
+    int32_t num_agents;
+    int32_t _pad;
+    double *loc;      /* [E*N*2] */
+    double *vel;      /* [E*N*2]  AG:14 velocity (float64) */
+    double *tgt;      /* [E*N*2] */
+    double *init_d;   /* [E*N] */
+    double *prev_d;   /* [E*N] */
+    uint8_t *flags;   /* [E*N]  bit0 done (AG:19), bit1 collided (AG:20) */
+    uint32_t *counters; /* [E*4] steps, target_reach_count, collision_count, episode index */
+    uint8_t *f64pos;  /* [E] */
+} uavo_state;
+
+/* MT19937 with numpy's legacy seeding, so that uavo_reset_mt() consumes the same stream as the
+ * reference's np.random.uniform calls after np.random.seed(seed). */
+typedef struct { uint32_t mt[624]; int32_t idx; } uavo_mt;
+void uavo_mt_seed(uavo_mt *g, uint32_t seed);
+double uavo_mt_double(uavo_mt *g);
+
+/* Philox4x32-10 (the generator the device reset kernel uses). out[4]. */
+void uavo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* MUW:116-175.  One env, draws from the MT stream.  circular!=0 applies MUW:157-163. */
+void uavo_reset_mt(const uavo_config *cfg, uavo_state *st, int64_t env, uavo_mt *g, int circular);
+/* Same rejection rules, draws from Philox keyed by (seed) with counter (global_env, episode, draw):
+ * restatement of the device reset kernel's generator for bit-exact comparison with it.
+ * mask==NULL resets all envs; else only envs with mask[e]!=0.  env_offset = first global env id. */
+void uavo_reset_philox(const uavo_config *cfg, uavo_state *st, const uint8_t *mask, uint64_t seed,
+                       int64_t env_offset, int nthreads);
+
+/* MUW:60-109 for every agent of every env: obs[(e*N+i)*10 + k] (float64 like the reference). */
+void uavo_observe(const uavo_config *cfg, const uavo_state *st, double *obs, int nthreads);
+
+/* MUW:177-241 on every env.  actions [(e*N+i)*2] float64 (float32 callers widen exactly).
+ * Outputs: obs [E*N*10] f64, reward [E*N] f64, done [E*N] u8. */
+void uavo_step(const uavo_config *cfg, uavo_state *st, const double *actions, int evaluate,
+               double *obs, double *reward, uint8_t *done, int nthreads);
+
+/* ---- UAVWorld2D (UW) ---- */
+typedef struct {
+    double x_size, y_size, max_speed, max_acceleration, tau;
+} uavo_uw_config;
+
+typedef struct {
+    int64_t num_envs;
+    double *loc;     /* [E*2] float32-representable (UW:121) */
+    double *vel;     /* [E*2] */
+    double *tgt;     /* [E*2] */
+    double *init_d;  /* [E] */
+    double *prev_d;  /* [E] */
+    uint32_t *steps; /* [E] */
+    uint32_t *episode; /* [E] reset count, Philox counter word 3 */
+    uint8_t *vel_f32; /* [E] 1 while velocity is still the float32 array drawn by reset (UW:122) */
+} uavo_uw_state;
+
+void uavo_uw_reset_mt(const uavo_uw_config *cfg, uavo_uw_state *st, int64_t env, uavo_mt *g);
+void uavo_uw_reset_philox(const uavo_uw_config *cfg, uavo_uw_state *st, const uint8_t *mask,
+                          uint64_t seed, int64_t env_offset, int nthreads);
+void uavo_uw_observe(const uavo_uw_config *cfg, const uavo_uw_state *st, double *obs, int nthreads);
+/* actions [E*2] f64; action_is_f32: the caller's array dtype was float32 (matters only on the first
+ * step after reset, see UW:142 under NEP 50).  reward f64 (value of the np.float32 the reference
+ * returns), done u8, info_distance [E] (UW:114-117). */
+void uavo_uw_step(const uavo_uw_config *cfg, uavo_uw_state *st, const double *actions,
+                  int action_is_f32, double *obs, double *reward, uint8_t *done,
+                  double *info_distance, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
