@@ -1,0 +1,111 @@
+"""ctypes binding of libuavx.so (include/uavx.h).  There is NO fallback: if the HIP library is
+missing or no MI355X is visible, every entry point raises."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libuavx.so")
+
+OBS_DIM = 10
+UW_OBS_DIM = 4
+MAX_AGENTS = 64
+FLAG_DONE, FLAG_COLLIDED, FLAG_VEL_F32 = 1, 2, 4
+F32, F64 = 0, 1
+
+# every symbol include/uavx.h declares (tests check the built library exports each of them)
+SYMBOLS = (
+    "uavx_version", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
+    "uavx_num_agents", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
+    "uavx_set_state", "uavx_get_metrics", "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
+    "uavx_uw_reset", "uavx_uw_step", "uavx_uw_observe", "uavx_uw_get_state", "uavx_uw_set_state",
+)
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("max_speed", ctypes.c_double),
+                ("max_acceleration", ctypes.c_double), ("collider_radius", ctypes.c_double),
+                ("d_sense", ctypes.c_double), ("tau", ctypes.c_double), ("num_agents", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class UWConfig(ctypes.Structure):
+    _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("max_speed", ctypes.c_double),
+                ("max_acceleration", ctypes.c_double), ("tau", ctypes.c_double)]
+
+
+class StateView(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("loc", "vel", "tgt", "init_d", "prev_d", "flags", "counters")]
+
+
+UWStateView = StateView  # same field list (uavx_uw_state_view)
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc build of csrc/ into csrc/libuavx.so (gfx950).  Cross-compiles without a GPU."""
+    args = ["make", "-C", CSRC]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {CSRC}` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the env step path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
+    L.uavx_version.restype = i32
+    L.uavx_strerror.restype = ctypes.c_char_p
+    L.uavx_strerror.argtypes = [i32]
+    L.uavx_create.argtypes = [ctypes.POINTER(Config), i64, i64, i32, ctypes.POINTER(vp)]
+    L.uavx_destroy.argtypes = [vp]
+    L.uavx_last_error.argtypes = [vp]
+    L.uavx_last_error.restype = ctypes.c_char_p
+    L.uavx_num_envs.argtypes = [vp]
+    L.uavx_num_envs.restype = i64
+    L.uavx_num_agents.argtypes = [vp]
+    L.uavx_reset.argtypes = [vp, vp, u64, vp, vp]
+    L.uavx_step.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    L.uavx_step_k.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.uavx_observe.argtypes = [vp, vp, vp]
+    L.uavx_get_state.argtypes = [vp, ctypes.POINTER(StateView), vp]
+    L.uavx_set_state.argtypes = [vp, ctypes.POINTER(StateView), vp]
+    L.uavx_get_metrics.argtypes = [vp, vp, vp]
+    L.uavx_uw_create.argtypes = [ctypes.POINTER(UWConfig), i64, i64, i32, ctypes.POINTER(vp)]
+    L.uavx_uw_destroy.argtypes = [vp]
+    L.uavx_uw_last_error.argtypes = [vp]
+    L.uavx_uw_last_error.restype = ctypes.c_char_p
+    L.uavx_uw_reset.argtypes = [vp, vp, u64, vp, vp]
+    L.uavx_uw_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.uavx_uw_observe.argtypes = [vp, vp, vp]
+    L.uavx_uw_get_state.argtypes = [vp, ctypes.POINTER(UWStateView), vp]
+    L.uavx_uw_set_state.argtypes = [vp, ctypes.POINTER(UWStateView), vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("uavx_version",):
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def check(rc, handle=None, uw=False):
+    if rc == 0:
+        return
+    L = load()
+    msg = L.uavx_strerror(rc).decode()
+    if handle:
+        detail = (L.uavx_uw_last_error if uw else L.uavx_last_error)(handle)
+        if detail:
+            msg += ": " + detail.decode()
+    if rc == -1:
+        raise ValueError("uavx: " + msg)
+    raise RuntimeError("uavx: " + msg)

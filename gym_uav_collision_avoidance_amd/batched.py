@@ -1,0 +1,380 @@
+"""Batched (vector) environments: E independent worlds advanced by one HIP kernel launch per step.
+
+This is the new surface the MI355X build adds on top of the reference's single-env gym API
+(SURVEY.md §8b): tensors in, tensors out, all resident in HBM, no host synchronisation on the step
+path.  Buffers are PyTorch-ROCm tensors (zero-copy: the kernels read/write `tensor.data_ptr()`);
+any object exposing `__hip_array_interface__` / `__cuda_array_interface__` is accepted as input.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spaces import Box
+
+_TORCH_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+class HipArray:
+    """Zero-copy view of a device tensor that publishes `__hip_array_interface__` (same schema as
+    the CUDA array interface v3) next to torch's own `__cuda_array_interface__`/DLPack."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def __hip_array_interface__(self):
+        t = self.tensor
+        typestr = {torch.float32: "<f4", torch.float64: "<f8", torch.uint8: "|u1", torch.bool: "|b1",
+                   torch.uint32: "<u4", torch.int32: "<i4", torch.int64: "<i8"}[t.dtype]
+        return dict(shape=tuple(t.shape), typestr=typestr, data=(t.data_ptr(), False), version=3,
+                    strides=None if t.is_contiguous() else tuple(s * t.element_size() for s in t.stride()),
+                    stream=None)
+
+    __cuda_array_interface__ = __hip_array_interface__
+
+
+def _device_index(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("uavx: no MI355X/HIP device visible to PyTorch; the batched env has no CPU fallback")
+    if device is None:
+        return torch.cuda.current_device()
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError(f"uavx: device must be a HIP ('cuda') device, got {device!r}")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class _Base:
+    """Shared plumbing: device, stream, tensor argument checking."""
+
+    def _init_device(self, device):
+        self._L = _lib.load()
+        self._dev_index = _device_index(device)
+        self.device = torch.device("cuda", self._dev_index)
+        self._h = ctypes.c_void_p()
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _actions_arg(self, actions, shape):
+        """-> (tensor kept alive, dtype code).  float32/float64, contiguous, on self.device."""
+        if isinstance(actions, torch.Tensor):
+            t = actions
+        elif hasattr(actions, "__hip_array_interface__") and not hasattr(actions, "__array__"):
+            t = torch.as_tensor(HipArrayAdapter(actions), device=self.device)
+        elif hasattr(actions, "__cuda_array_interface__"):
+            t = torch.as_tensor(actions, device=self.device)
+        else:
+            a = np.asarray(actions)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if t.dtype not in _TORCH_DT:
+            raise ValueError(f"uavx: actions must be float32 or float64, got {t.dtype}")
+        if t.device != self.device:
+            raise ValueError(f"uavx: actions live on {t.device}, env is on {self.device}")
+        if tuple(t.shape) != tuple(shape):
+            if t.numel() != int(np.prod(shape)):
+                raise ValueError(f"uavx: actions have shape {tuple(t.shape)}, expected {tuple(shape)}")
+            t = t.reshape(shape)
+        if not t.is_contiguous():
+            t = t.contiguous()
+        return t, _TORCH_DT[t.dtype]
+
+    def _out(self, t, shape, dtype, name):
+        if t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise ValueError(f"uavx: `{name}` must be a contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}")
+        return t
+
+
+class HipArrayAdapter:
+    """Lets torch.as_tensor consume an object that only publishes `__hip_array_interface__`."""
+
+    def __init__(self, obj):
+        self._obj = obj
+        self.__cuda_array_interface__ = obj.__hip_array_interface__
+
+
+class BatchedMultiUAVWorld2D(_Base):
+    """E x MultiUAVWorld2D (MUW:10).  Constructor keywords match MUW:13.
+
+    step()/reset() return views of internal HBM buffers; observations are double-buffered so the
+    previous step's `obs` stays valid while the next one is produced (replay tuples (s, a, r, s'),
+    test_sac_multi.py:101-105)."""
+
+    def __init__(self, num_envs, x_size=50.0, y_size=50.0, max_speed=10.0, max_acceleration=5.0, num_agents=4,
+                 collider_radius=1.0, d_sense=15, device=None, env_offset=0, seed=0):
+        self._init_device(device)
+        if not (1 <= int(num_agents) <= _lib.MAX_AGENTS):
+            raise ValueError(f"uavx: num_agents must be in [1, {_lib.MAX_AGENTS}]")
+        self.num_envs, self.num_agents = int(num_envs), int(num_agents)
+        self.x_size, self.y_size = float(x_size), float(y_size)
+        self.max_speed = np.array([max_speed, max_speed], dtype=np.float64)            # MUW:21
+        self.min_speed = -self.max_speed
+        self.max_acceleratoin = np.array([max_acceleration, max_acceleration], dtype=np.float64)  # sic, MUW:23
+        self.min_acceleratoin = -self.max_acceleratoin
+        self.map_diagonal_size = float(np.hypot(x_size, y_size))                         # MUW:17
+        self.min_location = np.array([-x_size / 2.0, -y_size / 2.0])
+        self.max_location = np.array([x_size / 2.0, y_size / 2.0])
+        self.tau = 0.02                                                                  # MUW:26
+        self.collider_radius, self.d_sense = collider_radius, d_sense
+        self.env_offset, self.seed = int(env_offset), int(seed)
+        # MUW:44-47 (low[9] = 1 is the reference's own typo; kept for space equality)
+        self.observation_space = Box(np.array([0, -1, 0, -1, 0, -1, -1, 0, -1, 1]), np.ones(10), shape=(10,),
+                                     dtype=np.float32)
+        self.action_space = Box(-max_speed, max_speed, shape=(2,), dtype=np.float32)
+        cfg = _lib.Config(x_size, y_size, max_speed, max_acceleration, collider_radius, float(d_sense), self.tau,
+                          self.num_agents, 0)
+        _lib.check(self._L.uavx_create(ctypes.byref(cfg), self.num_envs, self.env_offset, self._dev_index,
+                                       ctypes.byref(self._h)))
+        E, N = self.num_envs, self.num_agents
+        with torch.cuda.device(self.device):
+            self._obs = [torch.zeros((E, N, _lib.OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._rew = torch.zeros((E, N), dtype=torch.float32, device=self.device)
+            self._done = torch.zeros((E, N), dtype=torch.uint8, device=self.device)
+        self._flip = 0
+        self._resets = 0
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.uavx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _next_obs_buf(self):
+        self._flip ^= 1
+        return self._obs[self._flip]
+
+    # -- MUW:116-175 -------------------------------------------------------------------------------
+    def reset(self, mask=None, seed=None, out=None):
+        """Resets the envs selected by `mask` (bool/uint8 [E] device tensor; None = all) with the
+        on-device Philox sampler and returns the observations of all envs, [E, N, 10] float32."""
+        if seed is not None:
+            self.seed = int(seed)
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device)
+            if m.dtype == torch.bool:
+                m = m.to(torch.uint8)
+            m = self._out(m.contiguous(), (self.num_envs,), torch.uint8, "mask")
+        obs = self._next_obs_buf() if out is None else self._out(out, self._obs[0].shape, torch.float32, "out")
+        _lib.check(self._L.uavx_reset(self._h, None if m is None else m.data_ptr(), self.seed, obs.data_ptr(),
+                                      self._stream()), self._h)
+        self._resets += 1
+        return obs
+
+    # -- MUW:177-241 -------------------------------------------------------------------------------
+    def step(self, actions, evaluate=False, out=None):
+        """actions: [E, N, 2] float32/float64 velocity commands.  Returns (obs [E,N,10] f32,
+        rewards [E,N] f32, dones [E,N] bool, info) with info == {"distance": 0} (MUW:111-114)."""
+        a, code = self._actions_arg(actions, (self.num_envs, self.num_agents, 2))
+        if out is None:
+            obs, rew, done = self._next_obs_buf(), self._rew, self._done
+        else:
+            obs = self._out(out[0], self._obs[0].shape, torch.float32, "out[0]")
+            rew = self._out(out[1], self._rew.shape, torch.float32, "out[1]")
+            done = out[2]
+            if done.dtype == torch.bool:
+                done = done.view(torch.uint8)
+            done = self._out(done, self._done.shape, torch.uint8, "out[2]")
+        _lib.check(self._L.uavx_step(self._h, a.data_ptr(), code, int(bool(evaluate)), obs.data_ptr(),
+                                     rew.data_ptr(), done.data_ptr(), self._stream()), self._h)
+        return obs, rew, done.view(torch.bool), {"distance": 0}
+
+    def step_k(self, action_tape, evaluate=False, tape_out=False):
+        """K steps in one launch from an action tape [K, E, N, 2] (open-loop rollouts, benchmarks).
+        tape_out=False returns the last step's (obs, rew, done); True returns [K, ...] tapes."""
+        K = int(action_tape.shape[0])
+        a, code = self._actions_arg(action_tape, (K, self.num_envs, self.num_agents, 2))
+        E, N = self.num_envs, self.num_agents
+        if tape_out:
+            obs = torch.empty((K, E, N, _lib.OBS_DIM), dtype=torch.float32, device=self.device)
+            rew = torch.empty((K, E, N), dtype=torch.float32, device=self.device)
+            done = torch.empty((K, E, N), dtype=torch.uint8, device=self.device)
+        else:
+            obs, rew, done = self._next_obs_buf(), self._rew, self._done
+        _lib.check(self._L.uavx_step_k(self._h, K, a.data_ptr(), code, int(bool(evaluate)), int(bool(tape_out)),
+                                       obs.data_ptr(), rew.data_ptr(), done.data_ptr(), self._stream()), self._h)
+        return obs, rew, done.view(torch.bool), {"distance": 0}
+
+    def observe(self, out=None):
+        obs = self._next_obs_buf() if out is None else self._out(out, self._obs[0].shape, torch.float32, "out")
+        _lib.check(self._L.uavx_observe(self._h, obs.data_ptr(), self._stream()), self._h)
+        return obs
+
+    # -- state exchange (AG:13-20 fields, MUW:166-168 counters) --------------------------------------
+    _STATE_SPEC = (("loc", torch.float32, 2), ("vel", torch.float64, 2), ("tgt", torch.float32, 2),
+                   ("init_d", torch.float32, 0), ("prev_d", torch.float32, 0), ("flags", torch.uint8, 0))
+
+    def get_state(self):
+        E, N = self.num_envs, self.num_agents
+        st = {}
+        for name, dt, last in self._STATE_SPEC:
+            st[name] = torch.empty((E, N, last) if last else (E, N), dtype=dt, device=self.device)
+        st["counters"] = torch.empty((E, 4), dtype=torch.int32, device=self.device)
+        view = _lib.StateView(*[st[n].data_ptr() for n in ("loc", "vel", "tgt", "init_d", "prev_d", "flags", "counters")])
+        _lib.check(self._L.uavx_get_state(self._h, ctypes.byref(view), self._stream()), self._h)
+        return st
+
+    def set_state(self, **fields):
+        """Overwrites any subset of loc, vel, tgt, init_d, prev_d, flags, counters (host or device arrays)."""
+        E, N = self.num_envs, self.num_agents
+        keep, ptrs = [], {}
+        spec = {n: (dt, (E, N, last) if last else (E, N)) for n, dt, last in self._STATE_SPEC}
+        spec["counters"] = (torch.int32, (E, 4))
+        for name, val in fields.items():
+            if name not in spec:
+                raise ValueError(f"uavx: unknown state field {name!r}")
+            dt, shape = spec[name]
+            if isinstance(val, torch.Tensor):
+                t = val.to(device=self.device, dtype=dt)
+            else:
+                arr = np.asarray(val)
+                if name == "counters":
+                    arr = arr.astype(np.int64).astype(np.int32)
+                t = torch.from_numpy(np.ascontiguousarray(arr)).to(device=self.device, dtype=dt)
+            t = t.reshape(shape).contiguous()
+            keep.append(t)
+            ptrs[name] = t.data_ptr()
+        view = _lib.StateView(*[ptrs.get(n) for n in ("loc", "vel", "tgt", "init_d", "prev_d", "flags", "counters")])
+        _lib.check(self._L.uavx_set_state(self._h, ctypes.byref(view), self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()  # `keep` may be freed after return
+
+    def metrics(self):
+        """[E, 4] int32: steps, target_reach_count, collision_count, episode index (MUW:166-168)."""
+        c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.uavx_get_metrics(self._h, c.data_ptr(), self._stream()), self._h)
+        return c
+
+    @property
+    def steps(self):
+        return self.metrics()[:, 0]
+
+    @property
+    def target_reach_count(self):
+        return self.metrics()[:, 1]
+
+    @property
+    def collision_count(self):
+        return self.metrics()[:, 2]
+
+    def render(self, mode="human"):  # MUW:243 — no display on a compute node
+        return None
+
+
+class BatchedUAVWorld2D(_Base):
+    """E x UAVWorld2D (UW:11).  Constructor keywords match UW:14."""
+
+    def __init__(self, num_envs, x_size=100.0, y_size=100.0, agent_num=4, max_speed=12.0, max_acceleration=5.0,
+                 device=None, env_offset=0, seed=0):
+        self._init_device(device)
+        self.num_envs = int(num_envs)
+        self.x_size, self.y_size = float(x_size), float(y_size)
+        self.max_speed = np.array([max_speed, max_speed], dtype=np.float64)
+        self.min_speed = -self.max_speed
+        self.max_acceleratoin = np.array([max_acceleration, max_acceleration], dtype=np.float64)
+        self.min_acceleratoin = -self.max_acceleratoin
+        self.map_diagonal_size = float(np.hypot(x_size, y_size))
+        self.min_location = np.array([-x_size / 2.0, -y_size / 2.0])
+        self.max_location = np.array([x_size / 2.0, y_size / 2.0])
+        self.tau = 0.02
+        self.env_offset, self.seed = int(env_offset), int(seed)
+        self.observation_space = Box(np.array([0., -1., 0., -1.]), np.ones(4), shape=(4,), dtype=np.float32)  # UW:55
+        self.action_space = Box(-max_speed, max_speed, shape=(2,), dtype=np.float32)                            # UW:64
+        cfg = _lib.UWConfig(x_size, y_size, max_speed, max_acceleration, self.tau)
+        _lib.check(self._L.uavx_uw_create(ctypes.byref(cfg), self.num_envs, self.env_offset, self._dev_index,
+                                          ctypes.byref(self._h)))
+        E = self.num_envs
+        with torch.cuda.device(self.device):
+            self._obs = [torch.zeros((E, _lib.UW_OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._rew = torch.zeros((E,), dtype=torch.float32, device=self.device)
+            self._done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
+            self._info = torch.zeros((E,), dtype=torch.float32, device=self.device)
+        self._flip = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.uavx_uw_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _next_obs_buf(self):
+        self._flip ^= 1
+        return self._obs[self._flip]
+
+    def reset(self, mask=None, seed=None):  # UW:119-135
+        if seed is not None:
+            self.seed = int(seed)
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device)
+            if m.dtype == torch.bool:
+                m = m.to(torch.uint8)
+            m = self._out(m.contiguous(), (self.num_envs,), torch.uint8, "mask")
+        obs = self._next_obs_buf()
+        _lib.check(self._L.uavx_uw_reset(self._h, None if m is None else m.data_ptr(), self.seed, obs.data_ptr(),
+                                         self._stream()), self._h, uw=True)
+        return obs
+
+    def step(self, actions):  # UW:137-173
+        a, code = self._actions_arg(actions, (self.num_envs, 2))
+        obs = self._next_obs_buf()
+        _lib.check(self._L.uavx_uw_step(self._h, a.data_ptr(), code, obs.data_ptr(), self._rew.data_ptr(),
+                                        self._done.data_ptr(), self._info.data_ptr(), self._stream()), self._h, uw=True)
+        return obs, self._rew, self._done.view(torch.bool), {"distance": self._info}
+
+    def observe(self):
+        obs = self._next_obs_buf()
+        _lib.check(self._L.uavx_uw_observe(self._h, obs.data_ptr(), self._stream()), self._h, uw=True)
+        return obs
+
+    _STATE_SPEC = (("loc", torch.float32, (2,)), ("vel", torch.float64, (2,)), ("tgt", torch.float32, (2,)),
+                   ("init_d", torch.float32, ()), ("prev_d", torch.float32, ()), ("flags", torch.uint8, ()),
+                   ("counters", torch.int32, (2,)))
+
+    def get_state(self):
+        st = {n: torch.empty((self.num_envs,) + tail, dtype=dt, device=self.device) for n, dt, tail in self._STATE_SPEC}
+        view = _lib.UWStateView(*[st[n].data_ptr() for n, _, _ in self._STATE_SPEC])
+        _lib.check(self._L.uavx_uw_get_state(self._h, ctypes.byref(view), self._stream()), self._h, uw=True)
+        return st
+
+    def set_state(self, **fields):
+        spec = {n: (dt, (self.num_envs,) + tail) for n, dt, tail in self._STATE_SPEC}
+        keep, ptrs = [], {}
+        for name, val in fields.items():
+            if name not in spec:
+                raise ValueError(f"uavx: unknown state field {name!r}")
+            dt, shape = spec[name]
+            if isinstance(val, torch.Tensor):
+                t = val.to(device=self.device, dtype=dt)
+            else:
+                arr = np.asarray(val)
+                if name == "counters":
+                    arr = arr.astype(np.int64).astype(np.int32)
+                t = torch.from_numpy(np.ascontiguousarray(arr)).to(device=self.device, dtype=dt)
+            t = t.reshape(shape).contiguous()
+            keep.append(t)
+            ptrs[name] = t.data_ptr()
+        view = _lib.UWStateView(*[ptrs.get(n) for n, _, _ in self._STATE_SPEC])
+        _lib.check(self._L.uavx_uw_set_state(self._h, ctypes.byref(view), self._stream()), self._h, uw=True)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    @property
+    def steps(self):
+        return self.get_state()["counters"][:, 0]
+
+    def render(self, mode="human"):
+        return None

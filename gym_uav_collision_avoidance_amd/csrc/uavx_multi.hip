@@ -1,0 +1,686 @@
+// uavx_multi.hip — E x MultiUAVWorld2D on one MI355X: fused step / reset / observe kernels and the
+// C ABI of include/uavx.h.  Hand-written for gfx950 (wave64, LDS-staged neighbour exchange).
+//
+// Reference semantics (cited per block): MUW = gym_uav_collision_avoidance/envs/multi_uav_world_2d.py,
+// AG = .../uav_agent.py of dazchi/gym-uav-collision-avoidance.
+//
+// Work mapping.  One LANE per agent, floor(64/N) whole envs per WAVEFRONT (one env per wave at
+// N > 32), so an env never spans two waves and all cross-agent traffic stays inside the wave:
+//   1. every lane integrates its own agent (float64 velocity, float32 position, AG:23-36) — the
+//      reference's sequential loop over agents (MUW:181) has no real dependency here because an
+//      agent's motion only reads its own state;
+//   2. old + new position and heading of every agent are staged in LDS (20 B per lane);
+//   3. every lane scans the N-1 other agents of its env from LDS: the Gauss-Seidel rule "agents
+//      j<i already moved, j>i not yet" (MUW:181-231) becomes a per-pair select between the staged
+//      new/old position; min-distance feeds the collision tests, the two nearest at final positions
+//      feed the observation (AG:44-64, MUW:75-95);
+//   4. reward / collision / termination / finish() per lane (MUW:188-231, AG:38-42);
+//   5. the 10 observation floats per agent are transposed through LDS so the wave writes its
+//      2560-byte obs block with 16-byte-per-lane contiguous stores.
+// HBM layout (agent slot a = e*N + i, agent fastest => lane-contiguous):
+//   dyn  float4[A]  {x, y, prev_d, flags}   read+write   16 B
+//   vel  double2[A] {vx, vy}                read+write   16 B
+//   goal float[3A]  {tx, ty, init_d}        read         12 B
+//   per-env uint32 steps[E] (r/w by the env's first lane), reach[E] / coll[E] (atomics on the rare
+//   events), episode[E] (reset only).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/uavx.h"
+#include "uavx_device.hpp"
+
+namespace uavx {
+
+struct MultiParams {
+    double tau, amax, vmax;
+    double lox, loy, hix, hiy;
+    double speed_sq_lim;  // ‖v‖ < 0.2 (MUW:218)  <=>  fma(vy,vy,vx*vx) < speed_sq_lim
+    float two_r;          // float32(2*collider_radius): np.float32 <= python float compares in f32
+    float d_sense;        // float32(d_sense)
+    float vmax_norm;      // ‖(max_speed,max_speed)‖  MUW:62,183
+    float inv_diag;       // 1/‖(x_size,y_size)‖      MUW:17,68
+    float two_r_reset;    // same threshold, reset rejection (MUW:135,146,151)
+    int N, epw, magic;    // agents per env, envs per wave, ceil(65536/N)+... for lane/N
+    int64_t E, env_offset;
+    float4 *dyn;
+    double2 *vel;
+    float *goal;
+    uint32_t *steps, *reach, *coll, *episode;
+};
+
+struct LaneMap {
+    int lane, wib;   // lane in wave, wave in block
+    int g, i, base;  // env group within the wave, agent index, first lane of the group
+    bool active;
+    int64_t e, a;    // env, agent slot
+    int64_t a0;      // first agent slot of this wave
+    int cnt;         // active agent slots in this wave (contiguous from a0)
+};
+
+template <int NT>
+__device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
+    LaneMap m;
+    const int N = NT ? NT : p.N;
+    const int epw = NT ? (kWave / NT) : p.epw;
+    m.lane = threadIdx.x & (kWave - 1);
+    m.wib = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + m.wib;
+    if (NT) {
+        m.g = m.lane / NT;
+        m.i = m.lane % NT;
+    } else {
+        m.g = (m.lane * p.magic) >> 16;  // floor(lane / N) for lane < 64
+        m.i = m.lane - m.g * N;
+    }
+    const int64_t e0 = wave * epw;
+    m.e = e0 + m.g;
+    m.active = (m.g < epw) && (m.e < p.E);
+    m.base = m.active ? m.g * N : 0;  // idle lanes still execute the LDS scan: keep it in bounds
+    m.a = m.e * N + m.i;
+    m.a0 = e0 * N;
+    int64_t envs_here = p.E - e0;
+    envs_here = envs_here < 0 ? 0 : (envs_here > epw ? epw : envs_here);
+    m.cnt = (int)envs_here * N;
+    return m;
+}
+
+struct AgentRegs {
+    float x, y, prev_d;
+    uint32_t flags;
+    float tx, ty, init_d;
+    double vx, vy;
+};
+
+struct Lds {
+    float4 pos[kWavesPerBlock][kWave];            // {old.x, old.y, new.x, new.y}
+    float theta[kWavesPerBlock][kWave];           // heading atan2(vy, vx)
+    float obs[kWavesPerBlock][kWave * UAVX_OBS_DIM];
+};
+
+__device__ __forceinline__ void load_agent(const MultiParams &p, int64_t a, AgentRegs &s) {
+    const float4 d = p.dyn[a];
+    const double2 v = p.vel[a];
+    s.x = d.x; s.y = d.y; s.prev_d = d.z; s.flags = __float_as_uint(d.w);
+    s.vx = v.x; s.vy = v.y;
+    s.tx = p.goal[3 * a + 0]; s.ty = p.goal[3 * a + 1]; s.init_d = p.goal[3 * a + 2];
+}
+__device__ __forceinline__ void store_agent(const MultiParams &p, int64_t a, const AgentRegs &s) {
+    p.dyn[a] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags));
+    p.vel[a] = make_double2(s.vx, s.vy);
+}
+
+// Two nearest other agents strictly within d_sense at FINAL positions, ascending, ties -> lower
+// index (AG:44-64 as used by MUW:75-95), plus — when STEP — the minimum in-range distance under the
+// Gauss-Seidel position rule (MUW:198-210 only compares the nearest ones against thresholds, so the
+// minimum decides both tests).
+struct Neigh {
+    float d1, d2, dx1, dy1, dx2, dy2;
+    int j1, j2;
+    float step_min;
+};
+
+template <int NT, bool STEP>
+__device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
+                                                 float ny) {
+    const int N = NT ? NT : p.N;
+    Neigh r;
+    r.d1 = r.d2 = INFINITY;
+    r.dx1 = r.dy1 = r.dx2 = r.dy2 = 0.f;
+    r.j1 = r.j2 = -1;
+    r.step_min = INFINITY;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const float4 q = lds.pos[m.wib][m.base + j];
+        const float dxn = q.z - nx, dyn = q.w - ny;  // target_agent.location - self.location (AG:51)
+        const float dn = norm32(dxn, dyn);
+        const bool other = (j != m.i);
+        if (STEP) {
+            const float dold = norm32(q.x - nx, q.y - ny);
+            const float ds = (j < m.i) ? dn : dold;  // j<i already moved this step, j>i not yet
+            if (other && ds < p.d_sense) r.step_min = fminf(r.step_min, ds);
+        }
+        if (other && dn < p.d_sense) {  // AG:52
+            if (dn < r.d1) {
+                r.d2 = r.d1; r.j2 = r.j1; r.dx2 = r.dx1; r.dy2 = r.dy1;
+                r.d1 = dn; r.j1 = j; r.dx1 = dxn; r.dy1 = dyn;
+            } else if (dn < r.d2) {
+                r.d2 = dn; r.j2 = j; r.dx2 = dxn; r.dy2 = dyn;
+            }
+        }
+    }
+    return r;
+}
+
+// MUW:60-109 in float32 (angles compared on the circle; see DESIGN.md numerics).
+__device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap &m, const Lds &lds, const Neigh &nb,
+                                             float speed, float theta, float dist_t, float dth, float o[10]) {
+    o[0] = speed / p.vmax_norm;      // MUW:62
+    o[1] = theta * kInvPi;           // MUW:64
+    o[2] = dist_t * p.inv_diag;      // MUW:68
+    o[3] = dth * kInvPi;             // MUW:72
+    if (nb.j1 >= 0) {
+        o[4] = nb.d1 / p.d_sense;                                           // MUW:77
+        o[5] = wrap_pi(atan2f(nb.dy1, nb.dx1) - theta) * kInvPi;            // MUW:78-81
+        o[6] = wrap_pi(lds.theta[m.wib][m.base + nb.j1] - theta) * kInvPi;  // MUW:82-85
+    } else {
+        o[4] = 1.f; o[5] = 1.f; o[6] = 0.f;  // (pi + theta) - theta wraps to +-pi -> +-1 (same point)
+    }
+    if (nb.j2 >= 0) {
+        o[7] = nb.d2 / p.d_sense;                                           // MUW:87
+        o[8] = wrap_pi(atan2f(nb.dy2, nb.dx2) - theta) * kInvPi;            // MUW:88-91
+        o[9] = wrap_pi(lds.theta[m.wib][m.base + nb.j2] - theta) * kInvPi;  // MUW:92-95
+    } else {
+        o[7] = 1.f; o[8] = 1.f; o[9] = 0.f;
+    }
+}
+
+// Wave-cooperative store of the wave's contiguous obs block: lane-major [64][10] in LDS -> 16-byte
+// (or 8-byte when the block base is only 8-byte aligned) contiguous global stores.
+template <int NT>
+__device__ __forceinline__ void store_obs_block(const LaneMap &m, Lds &lds, const float o[10], float *obs_out) {
+    float *stage = lds.obs[m.wib];
+    // lane k of the wave holds agent slot a0 + (k - idle lanes before it); with whole envs packed
+    // from lane 0 the active lanes are exactly [0, cnt) in slot order.
+    if (m.active) {
+        float2 *dst = reinterpret_cast<float2 *>(stage + m.lane * UAVX_OBS_DIM);
+#pragma unroll
+        for (int k = 0; k < 5; k++) dst[k] = make_float2(o[2 * k], o[2 * k + 1]);
+    }
+    wave_lds_sync();
+    const int nfloat = m.cnt * UAVX_OBS_DIM;
+    float *gbase = obs_out + m.a0 * UAVX_OBS_DIM;
+    // wave-uniform: the block base a0*40 B is 16-byte aligned unless a0 is odd (odd N) or the tape offset is
+    const bool vec4 = (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0;
+    if (vec4) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int f = (k * kWave + m.lane) * 4;
+            if (f + 3 < nfloat) {
+                *reinterpret_cast<float4 *>(gbase + f) = *reinterpret_cast<const float4 *>(stage + f);
+            } else {
+                for (int t = f; t < nfloat && t < f + 4; t++) gbase[t] = stage[t];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int f = (k * kWave + m.lane) * 2;
+            if (f + 1 < nfloat) *reinterpret_cast<float2 *>(gbase + f) = *reinterpret_cast<const float2 *>(stage + f);
+        }
+    }
+    wave_lds_sync();
+}
+
+// One env step for this lane's agent (state in registers).  MUW:177-241.
+template <int NT>
+__device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &m, Lds &lds, AgentRegs &s, double ax,
+                                           double ay, int evaluate, float o[10], float &rew, uint32_t &done_out,
+                                           uint32_t &reach_ev, uint32_t &coll_ev) {
+    const bool was_done = (s.flags & UAVX_FLAG_DONE) != 0;
+    const float ox = s.x, oy = s.y;
+    float pd = 0.f, d = 0.f;  // AG:24-25: a done agent returns (0, 0) and does not move
+    if (!was_done) {
+        axis_update(ax, p.tau, p.amax, p.vmax, s.vx, s.x);  // AG:26-29
+        axis_update(ay, p.tau, p.amax, p.vmax, s.vy, s.y);
+        pd = s.prev_d;                                       // AG:32
+    }
+    const float tdx = s.tx - s.x, tdy = s.ty - s.y;
+    const float dist_t = norm32(tdx, tdy);                   // AG:33 / MUW:67
+    if (!was_done) d = dist_t;
+    // heading; finish() only rescales the velocity (AG:40), so one atan2 serves reward and obs
+    const float theta = atan2f((float)s.vy, (float)s.vx);    // MUW:63,185
+    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);     // MUW:184-186 == MUW:69-71
+
+    if (m.active) {
+        lds.pos[m.wib][m.lane] = make_float4(ox, oy, s.x, s.y);
+        lds.theta[m.wib][m.lane] = theta;
+    }
+    wave_lds_sync();
+    const Neigh nb = scan_neighbours<NT, true>(p, m, lds, s.x, s.y);
+
+    // reward shaping, MUW:188-195 (float32; |error| << 1e-5)
+    float r = -0.01f * fminf(p.vmax_norm / s.init_d, 1.0f);  // MUW:189
+    r += 50.0f * ((pd - d) / p.vmax_norm);                   // MUW:190 (pd - d is a float32 subtraction there too)
+    const float frac = d / (1.5f * s.init_d);                // MUW:192,194
+    r *= (r > 0.f) ? (1.0f - frac) : (1.0f + frac);
+    r -= 0.01f * fabsf(dth);                                 // MUW:195
+
+    // collisions, MUW:197-210
+    const bool collision = nb.step_min <= p.two_r;           // MUW:203
+    if (collision) r = -2.0f;                                // MUW:204
+    coll_ev = 0;
+    if (nb.step_min <= 1.0f && !(s.flags & (UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED))) {  // MUW:207-208
+        coll_ev = 1;                                         // MUW:209
+        s.flags |= UAVX_FLAG_COLLIDED;                       // MUW:210
+    }
+    // termination, MUW:213-227
+    const double sq = fma(s.vy, s.vy, s.vx * s.vx);          // MUW:214 (np.linalg.norm's float64 dot)
+    const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);
+    float speed = sqrtf((float)sq);
+    reach_ev = 0;
+    if (d < 0.5f && !collision && sq < p.speed_sq_lim) {     // MUW:218
+        done_out = 1;
+        reach_ev = was_done ? 0u : 1u;                       // MUW:220-221
+        s.flags |= UAVX_FLAG_DONE;                           // AG:39
+        const double nv = sqrt(sq);                          // AG:40
+        double fx = s.vx / nv * 0.001, fy = s.vy / nv * 0.001;
+        if (fx != fx || fy != fy) { fx = 0.0; fy = 0.0; }    // AG:41-42
+        s.vx = fx; s.vy = fy;
+        speed = sqrtf((float)fma(fy, fy, fx * fx));
+        r += 10.0f;                                          // MUW:223
+    } else if (oob) {
+        done_out = evaluate ? 0u : 1u;                       // MUW:224-225
+    } else {
+        done_out = 0;
+    }
+    s.prev_d = d;                                            // MUW:229
+    rew = r;
+    assemble_obs(p, m, lds, nb, speed, theta, dist_t, dth, o);  // MUW:233-235
+}
+
+template <int NT, bool ACT64>
+__global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+                                                      int K, int tape_out, float *__restrict__ obs_out,
+                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
+    __shared__ Lds lds;
+    const int N = NT ? NT : p.N;
+    const LaneMap m = lane_map<NT>(p);
+    AgentRegs s = {};
+    if (m.active) load_agent(p, m.a, s);
+    const int64_t A = p.E * N;
+    uint32_t reach_acc = 0, coll_acc = 0;
+    for (int k = 0; k < K; k++) {
+        double ax = 0.0, ay = 0.0;
+        if (m.active) {
+            if (ACT64) {
+                const double2 a = reinterpret_cast<const double2 *>(actions)[k * A + m.a];
+                ax = a.x; ay = a.y;
+            } else {
+                const float2 a = reinterpret_cast<const float2 *>(actions)[k * A + m.a];
+                ax = (double)a.x; ay = (double)a.y;
+            }
+        }
+        float o[10], rew;
+        uint32_t dn, re, ce;
+        step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
+        reach_acc += re;
+        coll_acc += ce;
+        if (tape_out || k == K - 1) {
+            const int64_t off = tape_out ? (int64_t)k * A : 0;
+            if (m.active) {
+                rew_out[off + m.a] = rew;
+                done_out[off + m.a] = (uint8_t)dn;
+            }
+            store_obs_block<NT>(m, lds, o, obs_out + off * UAVX_OBS_DIM);
+        } else {
+            wave_lds_sync();
+        }
+    }
+    if (m.active) {
+        store_agent(p, m.a, s);
+        if (reach_acc) atomicAdd(&p.reach[m.e], reach_acc);  // MUW:221
+        if (coll_acc) atomicAdd(&p.coll[m.e], coll_acc);     // MUW:209
+        if (m.i == 0) p.steps[m.e] += (uint32_t)K;           // MUW:238
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *__restrict__ obs_out) {
+    __shared__ Lds lds;
+    const LaneMap m = lane_map<NT>(p);
+    AgentRegs s = {};
+    if (m.active) load_agent(p, m.a, s);
+    const float tdx = s.tx - s.x, tdy = s.ty - s.y;
+    const float dist_t = norm32(tdx, tdy);
+    const float theta = atan2f((float)s.vy, (float)s.vx);
+    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);
+    if (m.active) {
+        lds.pos[m.wib][m.lane] = make_float4(s.x, s.y, s.x, s.y);
+        lds.theta[m.wib][m.lane] = theta;
+    }
+    wave_lds_sync();
+    const Neigh nb = scan_neighbours<NT, false>(p, m, lds, s.x, s.y);
+    const float speed = sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
+    float o[10];
+    assemble_obs(p, m, lds, nb, speed, theta, dist_t, dth, o);
+    store_obs_block<NT>(m, lds, o, obs_out);
+}
+
+// MUW:116-168 — one lane per env (the rejection loops are sequential inside an env and reset is off
+// the per-step path); draws come from Philox keyed by (seed; global env, draw, episode).
+__global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint8_t *__restrict__ mask, uint64_t seed) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.E) return;
+    if (mask && !mask[e]) return;
+    const int N = p.N;
+    const uint64_t ge = (uint64_t)(p.env_offset + e);
+    PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[e], (uint32_t)seed, (uint32_t)(seed >> 32), 0u};
+    float4 *dyn = p.dyn + e * N;
+    float *goal = p.goal + 3 * e * N;
+    for (int i = 0; i < N; i++) {  // MUW:126-137
+        float x, y;
+        bool replicated = true;
+        while (replicated) {
+            rng.point32(p.lox, p.loy, p.hix, p.hiy, x, y);
+            replicated = false;
+            for (int j = 0; j < i; j++) {
+                const float4 o = dyn[j];
+                if (norm32(o.x - x, o.y - y) <= p.two_r_reset) { replicated = true; break; }  // MUW:135
+            }
+        }
+        dyn[i] = make_float4(x, y, 0.f, __uint_as_float(0u));  // MUW:122-123 clears done/collided
+        p.vel[e * N + i] = make_double2(0.0, 0.0);               // MUW:120
+    }
+    for (int i = 0; i < N; i++) {  // MUW:140-155
+        const float4 me = dyn[i];
+        float tx, ty;
+        bool replicated = true;
+        while (replicated) {
+            rng.point32(p.lox, p.loy, p.hix, p.hiy, tx, ty);
+            replicated = norm32(tx - me.x, ty - me.y) <= p.two_r_reset;  // MUW:146
+            for (int j = 0; j < i && !replicated; j++) {
+                if (norm32(goal[3 * j] - tx, goal[3 * j + 1] - ty) <= p.two_r_reset) replicated = true;  // MUW:151
+            }
+        }
+        const float d0 = norm32(tx - me.x, ty - me.y);  // MUW:154
+        goal[3 * i] = tx; goal[3 * i + 1] = ty; goal[3 * i + 2] = d0;
+        dyn[i] = make_float4(me.x, me.y, d0, __uint_as_float(0u));  // MUW:155 prev_distance = init_distance
+    }
+    p.steps[e] = 0; p.reach[e] = 0; p.coll[e] = 0;  // MUW:166-168
+    p.episode[e] += 1;
+}
+
+__global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_state_view v) {
+    const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t A = p.E * p.N;
+    if (a < A) {
+        const float4 d = p.dyn[a];
+        if (v.loc) { v.loc[2 * a] = d.x; v.loc[2 * a + 1] = d.y; }
+        if (v.prev_d) v.prev_d[a] = d.z;
+        if (v.flags) v.flags[a] = (uint8_t)__float_as_uint(d.w);
+        if (v.vel) { const double2 w = p.vel[a]; v.vel[2 * a] = w.x; v.vel[2 * a + 1] = w.y; }
+        if (v.tgt) { v.tgt[2 * a] = p.goal[3 * a]; v.tgt[2 * a + 1] = p.goal[3 * a + 1]; }
+        if (v.init_d) v.init_d[a] = p.goal[3 * a + 2];
+    }
+    if (a < p.E && v.counters) {
+        v.counters[4 * a + 0] = p.steps[a]; v.counters[4 * a + 1] = p.reach[a];
+        v.counters[4 * a + 2] = p.coll[a];  v.counters[4 * a + 3] = p.episode[a];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_state_view v) {
+    const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t A = p.E * p.N;
+    if (a < A) {
+        float4 d = p.dyn[a];
+        if (v.loc) { d.x = v.loc[2 * a]; d.y = v.loc[2 * a + 1]; }
+        if (v.prev_d) d.z = v.prev_d[a];
+        if (v.flags) d.w = __uint_as_float((uint32_t)v.flags[a]);
+        p.dyn[a] = d;
+        if (v.vel) p.vel[a] = make_double2(v.vel[2 * a], v.vel[2 * a + 1]);
+        if (v.tgt) { p.goal[3 * a] = v.tgt[2 * a]; p.goal[3 * a + 1] = v.tgt[2 * a + 1]; }
+        if (v.init_d) p.goal[3 * a + 2] = v.init_d[a];
+    }
+    if (a < p.E && v.counters) {
+        p.steps[a] = v.counters[4 * a + 0]; p.reach[a] = v.counters[4 * a + 1];
+        p.coll[a] = v.counters[4 * a + 2];  p.episode[a] = v.counters[4 * a + 3];
+    }
+}
+
+}  // namespace uavx
+
+// ------------------------------------------------------------------------------------------------
+// host side: handle + C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace uavx;
+
+struct uavx_handle {
+    uavx_config cfg;
+    MultiParams p;
+    int device;
+    void *slab;  // one allocation holding every state array
+    std::string err;
+};
+
+namespace {
+
+int fail(uavx_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+int hip_fail(uavx_handle *h, hipError_t e, const char *what) {
+    return fail(h, UAVX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define UAVX_HIP(h, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(h, e_, #call); \
+    } while (0)
+
+// smallest double s with sqrt(s) >= lim, so that  sqrt(s) < lim  <=>  s < result  (sqrt is
+// correctly rounded and monotone): lets the device test MUW:218's speed without a float64 sqrt.
+double sq_threshold(double lim) {
+    double s = lim * lim;
+    while (std::sqrt(s) >= lim) s = std::nextafter(s, 0.0);
+    while (std::sqrt(s) < lim) s = std::nextafter(s, INFINITY);
+    return s;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <int NT>
+int launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actions, int action_dtype, int evaluate, int K,
+                   int tape_out, float *obs, float *rew, uint8_t *done) {
+    if (action_dtype == UAVX_F64)
+        hipLaunchKernelGGL((step_kernel<NT, true>), grid, dim3(kBlock), 0, st, h->p, actions, evaluate, K, tape_out, obs,
+                           rew, done);
+    else
+        hipLaunchKernelGGL((step_kernel<NT, false>), grid, dim3(kBlock), 0, st, h->p, actions, evaluate, K, tape_out, obs,
+                           rew, done);
+    return 0;
+}
+
+dim3 wave_grid(const uavx_handle *h) {
+    const int64_t waves = (h->p.E + h->p.epw - 1) / h->p.epw;
+    return dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
+}
+
+// Launches go to the handle's device; the caller's current device is restored afterwards.
+struct DeviceGuard {
+    int prev = -1, want;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : want(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) err = hipSetDevice(want);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
+#define UAVX_ENTER(h)                                                     \
+    DeviceGuard guard_((h)->device);                                      \
+    if (guard_.err != hipSuccess) return hip_fail((h), guard_.err, "hipSetDevice")
+
+}  // namespace
+
+extern "C" {
+
+int uavx_version(void) { return UAVX_VERSION; }
+
+const char *uavx_strerror(int status) {
+    switch (status) {
+        case UAVX_OK: return "ok";
+        case UAVX_ERR_INVALID_ARG: return "invalid argument";
+        case UAVX_ERR_HIP: return "HIP runtime error";
+        case UAVX_ERR_NO_DEVICE: return "no HIP device";
+        case UAVX_ERR_UNSUPPORTED: return "unsupported";
+        case UAVX_ERR_ALLOC: return "allocation failed";
+        default: return "unknown status";
+    }
+}
+
+int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device, uavx_handle **out) {
+    if (!cfg || !out || num_envs <= 0 || env_offset < 0) return UAVX_ERR_INVALID_ARG;
+    if (cfg->num_agents < 1 || cfg->num_agents > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
+    if (!(cfg->tau > 0) || !(cfg->max_speed > 0) || !(cfg->max_acceleration > 0) || !(cfg->x_size > 0) ||
+        !(cfg->y_size > 0) || !(cfg->d_sense > 0) || !(cfg->collider_radius >= 0))
+        return UAVX_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UAVX_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return UAVX_ERR_INVALID_ARG;
+    uavx_handle *h = new (std::nothrow) uavx_handle();
+    if (!h) return UAVX_ERR_ALLOC;
+    h->cfg = *cfg;
+    h->device = device;
+    h->slab = nullptr;
+    MultiParams &p = h->p;
+    std::memset(&p, 0, sizeof p);
+    const int N = cfg->num_agents;
+    p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
+    p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
+    p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
+    p.speed_sq_lim = sq_threshold(0.2);
+    p.two_r = (float)(2 * cfg->collider_radius);
+    p.two_r_reset = p.two_r;
+    p.d_sense = (float)cfg->d_sense;
+    p.vmax_norm = (float)std::sqrt(std::fma(cfg->max_speed, cfg->max_speed, cfg->max_speed * cfg->max_speed));
+    p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
+    p.N = N;
+    p.epw = kWave / N;
+    p.magic = 65536 / N + 1;
+    p.E = num_envs;
+    p.env_offset = env_offset;
+
+    DeviceGuard guard(device);
+    hipError_t e = guard.err;
+    if (e != hipSuccess) { delete h; return UAVX_ERR_HIP; }
+    const size_t A = (size_t)num_envs * N, E = (size_t)num_envs;
+    size_t off = 0;
+    const size_t o_dyn = off;  off = align_up(off + A * sizeof(float4), 256);
+    const size_t o_vel = off;  off = align_up(off + A * sizeof(double2), 256);
+    const size_t o_goal = off; off = align_up(off + A * 3 * sizeof(float), 256);
+    const size_t o_steps = off; off = align_up(off + E * 4, 256);
+    const size_t o_reach = off; off = align_up(off + E * 4, 256);
+    const size_t o_coll = off;  off = align_up(off + E * 4, 256);
+    const size_t o_epi = off;   off = align_up(off + E * 4, 256);
+    e = hipMalloc(&h->slab, off);
+    if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
+    e = hipMemset(h->slab, 0, off);
+    if (e != hipSuccess) { (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP; }
+    char *b = static_cast<char *>(h->slab);
+    p.dyn = reinterpret_cast<float4 *>(b + o_dyn);
+    p.vel = reinterpret_cast<double2 *>(b + o_vel);
+    p.goal = reinterpret_cast<float *>(b + o_goal);
+    p.steps = reinterpret_cast<uint32_t *>(b + o_steps);
+    p.reach = reinterpret_cast<uint32_t *>(b + o_reach);
+    p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
+    p.episode = reinterpret_cast<uint32_t *>(b + o_epi);
+    *out = h;
+    return UAVX_OK;
+}
+
+int uavx_destroy(uavx_handle *h) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    if (h->slab) {
+        DeviceGuard guard(h->device);
+        (void)hipFree(h->slab);
+    }
+    delete h;
+    return UAVX_OK;
+}
+
+const char *uavx_last_error(const uavx_handle *h) { return h ? h->err.c_str() : "null handle"; }
+int64_t uavx_num_envs(const uavx_handle *h) { return h ? h->p.E : -1; }
+int uavx_num_agents(const uavx_handle *h) { return h ? h->p.N : -1; }
+
+static int launch_observe(uavx_handle *h, float *obs, hipStream_t st) {
+    const dim3 grid = wave_grid(h);
+    switch (h->p.N) {
+        case 1: hipLaunchKernelGGL((observe_kernel<1>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 2: hipLaunchKernelGGL((observe_kernel<2>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 4: hipLaunchKernelGGL((observe_kernel<4>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 8: hipLaunchKernelGGL((observe_kernel<8>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        default: hipLaunchKernelGGL((observe_kernel<0>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+    }
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_observe(uavx_handle *h, float *obs, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    if (!obs) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_observe: obs is NULL");
+    UAVX_ENTER(h);
+    return launch_observe(h, obs, static_cast<hipStream_t>(stream));
+}
+
+int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((h->p.E + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(reset_kernel, grid, dim3(kBlock), 0, st, h->p, mask, seed);
+    UAVX_HIP(h, hipGetLastError());
+    if (obs) return launch_observe(h, obs, st);
+    return UAVX_OK;
+}
+
+int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, int evaluate, int tape_out, float *obs,
+                float *rew, uint8_t *done, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    if (!actions || !obs || !rew || !done) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: NULL buffer");
+    if (k < 1) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_k: k < 1");
+    if (action_dtype != UAVX_F32 && action_dtype != UAVX_F64)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: action_dtype must be UAVX_F32 or UAVX_F64");
+    UAVX_ENTER(h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid = wave_grid(h);
+    switch (h->p.N) {
+        case 1: launch_step_nt<1>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        case 2: launch_step_nt<2>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        case 4: launch_step_nt<4>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        case 8: launch_step_nt<8>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        default: launch_step_nt<0>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+    }
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_step(uavx_handle *h, const void *actions, int action_dtype, int evaluate, float *obs, float *rew,
+              uint8_t *done, void *stream) {
+    return uavx_step_k(h, 1, actions, action_dtype, evaluate, 0, obs, rew, done, stream);
+}
+
+int uavx_get_state(uavx_handle *h, const uavx_state_view *dst, void *stream) {
+    if (!h || !dst) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    const int64_t A = h->p.E * h->p.N;
+    hipLaunchKernelGGL(get_state_kernel, dim3((unsigned)((A + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, *dst);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_set_state(uavx_handle *h, const uavx_state_view *src, void *stream) {
+    if (!h || !src) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    const int64_t A = h->p.E * h->p.N;
+    hipLaunchKernelGGL(set_state_kernel, dim3((unsigned)((A + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, *src);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_get_metrics(uavx_handle *h, uint32_t *counters, void *stream) {
+    if (!h || !counters) return UAVX_ERR_INVALID_ARG;
+    uavx_state_view v;
+    std::memset(&v, 0, sizeof v);
+    v.counters = counters;
+    return uavx_get_state(h, &v, stream);
+}
+
+}  // extern "C"

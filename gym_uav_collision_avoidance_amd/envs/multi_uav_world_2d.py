@@ -1,0 +1,123 @@
+"""Drop-in single-env façade of MultiUAVWorld2D (MUW:10) over the batched HIP path (E = 1).
+
+Same constructor keywords, attributes, list-valued returns and gym-0.24 call signatures as the
+reference, so run_multi.py:5-23 and the trainers' loops (test_sac_multi.py:62-119) drive it
+unchanged.  All arithmetic of step()/_get_obs() runs in the HIP kernels; the façade only converts
+between Python lists and device tensors.  reset() keeps the reference's contract of drawing from
+the process-global `np.random` stream in the same order (MUW:126-153), so a seeded script sees the
+same start/target layout as with the reference; the layout is then uploaded with uavx_set_state.
+"""
+import colorsys
+import math
+
+import numpy as np
+import torch
+
+from ..batched import BatchedMultiUAVWorld2D
+from ..spaces import Box
+from .uav_agent import UAVAgentView
+
+HARD_COLLISION_RADIUS = 0.5  # MUW:8
+
+
+def _norm32(v):
+    v = np.asarray(v, dtype=np.float32)
+    return np.sqrt(v[0] * v[0] + v[1] * v[1])
+
+
+class MultiUAVWorld2D:
+    metadata = {"render_fps": 1000}  # MUW:11
+
+    def __init__(self, x_size=50.0, y_size=50.0, max_speed=10.0, max_acceleration=5.0, num_agents=4,
+                 collider_radius=1.0, d_sense=15, device=None):
+        self._batched = BatchedMultiUAVWorld2D(1, x_size, y_size, max_speed, max_acceleration, num_agents,
+                                               collider_radius, d_sense, device=device)
+        b = self._batched
+        self.x_size, self.y_size, self.num_agents = x_size, y_size, num_agents
+        self.map_diagonal_size = b.map_diagonal_size
+        self.map_dimension = np.array([x_size, y_size])
+        self.min_location, self.max_location = b.min_location, b.max_location
+        self.max_speed, self.min_speed = b.max_speed, b.min_speed
+        self.max_acceleratoin, self.min_acceleratoin = b.max_acceleratoin, b.min_acceleratoin
+        self.tau = b.tau
+        self.collider_radius, self.d_sense = collider_radius, d_sense
+        self.observation_space: Box = b.observation_space
+        self.action_space: Box = b.action_space
+        self.agent_list = []
+        for i in range(num_agents):  # MUW:37-41
+            r, g, bl = colorsys.hsv_to_rgb(i / num_agents, 1.0, 1.0)
+            self.agent_list.append(UAVAgentView(self, i, (int(255 * r), int(255 * g), int(255 * bl)), max_speed,
+                                                max_acceleration, self.tau))
+        self.window = None
+        self.clock = None
+
+    # -- counters live on the device (MUW:166-168,209,221,238) ----------------------------------------
+    def _counter(self, k):
+        return int(self._batched.metrics()[0, k].item())
+
+    def _set_counter(self, k, v):
+        c = self._batched.metrics()
+        c[0, k] = int(v)
+        self._batched.set_state(counters=c)
+
+    steps = property(lambda s: s._counter(0), lambda s, v: s._set_counter(0, v))
+    target_reach_count = property(lambda s: s._counter(1), lambda s, v: s._set_counter(1, v))
+    collision_count = property(lambda s: s._counter(2), lambda s, v: s._set_counter(2, v))
+
+    def _get_info(self):
+        return {"distance": 0}  # MUW:111-114
+
+    def _obs_list(self, obs):
+        o = obs[0].cpu().numpy()
+        return [o[i].copy() for i in range(self.num_agents)]
+
+    def _draw_layout(self):
+        """Start/target points with the reference's rejection rules and np.random draw order."""
+        n, lo, hi = self.num_agents, self.min_location, self.max_location
+        two_r = 2 * self.collider_radius
+        loc = np.zeros((n, 2), np.float32)
+        tgt = np.zeros((n, 2), np.float32)
+        for i in range(n):  # MUW:126-137
+            while True:
+                cand = np.random.uniform(lo, high=hi, size=(2,)).astype(np.float32)
+                if all(_norm32(loc[j] - cand) > two_r for j in range(i)):
+                    break
+            loc[i] = cand
+        for i in range(n):  # MUW:140-153
+            while True:
+                cand = np.random.uniform(lo, high=hi, size=(2,)).astype(np.float32)
+                if _norm32(cand - loc[i]) > two_r and all(_norm32(tgt[j] - cand) > two_r for j in range(i)):
+                    break
+            tgt[i] = cand
+        return loc, tgt
+
+    def reset(self, return_info=False, circular=False):  # MUW:116
+        n = self.num_agents
+        loc, tgt = self._draw_layout()
+        if circular:
+            # MUW:157-163 places float64 points; device positions are float32 (numerics)
+            th = 2 * np.arange(n) * math.pi / n
+            loc = (20 * np.stack([np.cos(th), np.sin(th)], axis=1)).astype(np.float32)
+            tgt = (23 * np.stack([np.cos(th + math.pi), np.sin(th + math.pi)], axis=1)).astype(np.float32)
+        d = tgt - loc
+        init_d = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)  # MUW:154
+        self._batched.set_state(loc=loc[None], tgt=tgt[None], vel=np.zeros((1, n, 2)), init_d=init_d[None],
+                                prev_d=init_d[None], flags=np.zeros((1, n), np.uint8),
+                                counters=np.array([[0, 0, 0, int(self._batched.metrics()[0, 3].item()) + 1]]))
+        obs = self._obs_list(self._batched.observe())  # MUW:170-172
+        return (obs, self._get_info()) if return_info else obs
+
+    def step(self, n_action, evaluate=False):  # MUW:177
+        a = np.asarray([np.asarray(x, dtype=np.float64) for x in n_action], dtype=np.float64)
+        if a.shape != (self.num_agents, 2):
+            raise IndexError(f"n_action must hold {self.num_agents} actions of 2 components")
+        obs, rew, done, _ = self._batched.step(torch.from_numpy(a[None]).to(self._batched.device), evaluate=evaluate)
+        rew = rew[0].cpu().numpy()
+        done = done[0].cpu().numpy()
+        return (self._obs_list(obs), [float(r) for r in rew], [bool(d) for d in done], self._get_info())
+
+    def render(self, mode="human"):  # MUW:243 — pygame window replaced by a no-op (headless node)
+        return None
+
+    def close(self):  # MUW:333
+        self._batched.close()

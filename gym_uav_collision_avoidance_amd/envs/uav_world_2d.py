@@ -1,0 +1,61 @@
+"""Drop-in single-env façade of UAVWorld2D (UW:11) over the batched HIP path (E = 1); drives
+run.py:6-16 and test_sac.py-style loops unchanged.  reset() draws location, velocity and target
+from np.random in the reference's order (UW:121-126)."""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..batched import BatchedUAVWorld2D
+
+
+class UAVWorld2D:
+    metadata = {"render_fps": 1000}  # UW:12
+
+    def __init__(self, x_size=100.0, y_size=100.0, agent_num=4, max_speed=12.0, max_acceleration=5.0, device=None):
+        self._batched = BatchedUAVWorld2D(1, x_size, y_size, agent_num, max_speed, max_acceleration, device=device)
+        b = self._batched
+        self.x_size, self.y_size = x_size, y_size
+        self.map_diagonal_size = b.map_diagonal_size
+        self.map_dimension = np.array([x_size, y_size])
+        self.min_location, self.max_location = b.min_location, b.max_location
+        self.max_speed, self.min_speed = b.max_speed, b.min_speed
+        self.max_acceleratoin, self.min_acceleratoin = b.max_acceleratoin, b.min_acceleratoin
+        self.tau = b.tau
+        self.observation_space, self.action_space = b.observation_space, b.action_space
+        self.window = None
+        self.clock = None
+
+    @property
+    def steps(self):
+        return int(self._batched.steps[0].item())
+
+    def _get_info(self):  # UW:114-117
+        st = self._batched.get_state()
+        d = (st["tgt"][0] - st["loc"][0]).cpu().numpy()
+        return {"distance": np.sqrt(d[0] * d[0] + d[1] * d[1])}
+
+    def reset(self, return_info=False, options=None):  # UW:119
+        loc = np.random.uniform(self.min_location, high=self.max_location, size=(2,)).astype(np.float32)
+        vel = np.random.uniform(self.min_speed, high=self.max_speed, size=(2,)).astype(np.float32)
+        tgt = np.random.uniform(self.min_location, high=self.max_location, size=(2,)).astype(np.float32)
+        d = tgt - loc
+        init_d = np.sqrt(d[0] * d[0] + d[1] * d[1])
+        episode = int(self._batched.get_state()["counters"][0, 1].item()) + 1
+        self._batched.set_state(loc=loc[None], vel=vel.astype(np.float64)[None], tgt=tgt[None], init_d=[init_d],
+                                prev_d=[init_d], flags=[_lib.FLAG_VEL_F32], counters=[[0, episode]])
+        obs = self._batched.observe()[0].cpu().numpy().copy()
+        return (obs, self._get_info()) if return_info else obs
+
+    def step(self, action):  # UW:137
+        a = np.asarray(action)
+        if a.dtype != np.float32:
+            a = a.astype(np.float64)
+        obs, rew, done, info = self._batched.step(torch.from_numpy(np.ascontiguousarray(a.reshape(1, 2))).to(self._batched.device))
+        return (obs[0].cpu().numpy().copy(), np.float32(rew[0].item()), bool(done[0].item()),
+                {"distance": np.float32(info["distance"][0].item())})
+
+    def render(self, mode="human"):  # UW:175 — no-op on a headless node
+        return None
+
+    def close(self):  # UW:230
+        self._batched.close()

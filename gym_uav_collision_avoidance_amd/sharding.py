@@ -1,0 +1,53 @@
+"""Multi-GPU sharding by environment index: one process per GPU, rank r owns the
+global envs [offset, offset + count); the step path has NO communication (worlds are independent,
+MUW:36-41 builds a private agent_list per env).  The only collective is one gather of per-env
+episode metrics to rank 0 (RCCL over xGMI when the backend is "nccl"), serving the evaluation path
+that reads env.target_reach_count / env.collision_count before reset (test_sac_multi.py:164-165)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs, world_size, rank):
+    """Contiguous split of `total_envs` over `world_size` ranks; the first (total % world) ranks get
+    one extra env.  Returns (offset, count)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(total_envs), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def gather_episode_metrics(local, dst=0, group=None):
+    """Gathers per-env metric rows ([E_local, C] tensor; any dtype) from every rank to `dst` in global
+    env order.  Returns the concatenated [E_total, C] tensor on dst, None elsewhere.  Ranks may own
+    different numbers of envs (shard_range); rows are padded to the largest shard for the gather."""
+    if not dist.is_available() or not dist.is_initialized():
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    width = max(sizes)
+    padded = local
+    if local.shape[0] != width:
+        padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    padded = padded.contiguous()
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, gather_list=bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+def summarize_metrics(counters, num_agents):
+    """SR / CR as the reference's evaluation loop computes them (test_sac_multi.py:174-175) from
+    gathered [E, 4] counters (steps, target_reach_count, collision_count, episode)."""
+    c = counters.to(torch.float64)
+    episodes = c.shape[0]
+    return dict(success_rate=float(c[:, 1].sum() / (num_agents * episodes)),
+                collision_rate=float(c[:, 2].sum() / (num_agents * episodes)),
+                mean_steps=float(c[:, 0].mean()))

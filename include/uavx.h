@@ -1,0 +1,159 @@
+/* uavx.h — C ABI of libuavx.so: batched UAV collision-avoidance environments on MI355X (gfx950).
+ *
+ * The reference (dazchi/gym-uav-collision-avoidance) is pure Python and has NO FFI boundary; its
+ * boundary is the gym.Env API of two classes.  Each entry point below therefore cites the Python
+ * method it replaces (MUW = gym_uav_collision_avoidance/envs/multi_uav_world_2d.py,
+ * AG = .../uav_agent.py, UW = .../uav_world_2d.py) and INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to route those methods here.
+ *
+ * Conventions
+ *   - every function returns 0 (UAVX_OK) or a negative uavx_status; nothing throws across the ABI;
+ *     uavx_last_error(h) returns a message for the last failure on that handle.
+ *   - all buffer arguments are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr())
+ *     on the device the handle was created on; the library never allocates on the step path and
+ *     never synchronises: work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ *     null stream) and is complete when that stream reaches it.
+ *   - a handle is not thread-safe; use one handle per device / per caller thread.
+ *   - E = number of envs, N = agents per env, agent slot a = e*N + i (agent index fastest).
+ */
+#ifndef UAVX_H
+#define UAVX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVX_VERSION 1
+#define UAVX_OBS_DIM 10     /* MUW:98-109 */
+#define UAVX_UW_OBS_DIM 4   /* UW:107-112 */
+#define UAVX_MAX_AGENTS 64  /* one wavefront holds a whole env */
+
+#define UAVX_FLAG_DONE 1u      /* AG:19 */
+#define UAVX_FLAG_COLLIDED 2u  /* AG:20 */
+#define UAVX_FLAG_VEL_F32 4u   /* UW only: velocity is still reset()'s float32 draw (UW:122) */
+
+typedef enum {
+    UAVX_OK = 0,
+    UAVX_ERR_INVALID_ARG = -1,
+    UAVX_ERR_HIP = -2,          /* a HIP runtime call failed; message has hipGetErrorString */
+    UAVX_ERR_NO_DEVICE = -3,
+    UAVX_ERR_UNSUPPORTED = -4,
+    UAVX_ERR_ALLOC = -5
+} uavx_status;
+
+typedef enum { UAVX_F32 = 0, UAVX_F64 = 1 } uavx_dtype;
+
+/* MultiUAVWorld2D.__init__ keyword arguments (MUW:13) + tau (MUW:26). */
+typedef struct {
+    double x_size, y_size;
+    double max_speed, max_acceleration;
+    double collider_radius, d_sense;
+    double tau;
+    int32_t num_agents;
+    int32_t reserved;
+} uavx_config;
+
+/* UAVWorld2D.__init__ keyword arguments (UW:14) + tau (UW:26). */
+typedef struct {
+    double x_size, y_size, max_speed, max_acceleration, tau;
+} uavx_uw_config;
+
+/* State exchange view (uavx_get_state / uavx_set_state): plain SoA device arrays, any pointer may
+ * be NULL to skip that component.  Mirrors the UAVAgent fields (AG:13-20) and the env counters
+ * (MUW:166-168). */
+typedef struct {
+    float *loc;         /* [E*N*2] AG:13  location (float32, MUW:126) */
+    double *vel;        /* [E*N*2] AG:14  velocity (float64) */
+    float *tgt;         /* [E*N*2] AG:16  target_location */
+    float *init_d;      /* [E*N]   AG:17  init_distance */
+    float *prev_d;      /* [E*N]   AG:18  prev_distance */
+    uint8_t *flags;     /* [E*N]   UAVX_FLAG_* */
+    uint32_t *counters; /* [E*4]   steps, target_reach_count, collision_count, episode index */
+} uavx_state_view;
+
+typedef struct {
+    float *loc;        /* [E*2] UW:121 */
+    double *vel;       /* [E*2] UW:122 */
+    float *tgt;        /* [E*2] UW:126 */
+    float *init_d;     /* [E]   UW:129 */
+    float *prev_d;     /* [E]   UW:130 */
+    uint8_t *flags;    /* [E]   UAVX_FLAG_VEL_F32 */
+    uint32_t *counters; /* [E*2] steps (UW:131), episode index */
+} uavx_uw_state_view;
+
+typedef struct uavx_handle uavx_handle;       /* E x MultiUAVWorld2D */
+typedef struct uavx_uw_handle uavx_uw_handle; /* E x UAVWorld2D */
+
+int uavx_version(void);
+const char *uavx_strerror(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * MultiUAVWorld2D
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces MultiUAVWorld2D.__init__ (MUW:13-58) for num_envs independent worlds on HIP device
+ * `device`.  env_offset = global index of this handle's env 0 (multi-GPU sharding by env index:
+ * Philox reset streams are keyed by global env id so results do not depend on the shard count). */
+int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device,
+                uavx_handle **out);
+int uavx_destroy(uavx_handle *h);
+const char *uavx_last_error(const uavx_handle *h);
+int64_t uavx_num_envs(const uavx_handle *h);
+int uavx_num_agents(const uavx_handle *h);
+
+/* Replaces MultiUAVWorld2D.reset (MUW:116-175) for the envs with mask[e] != 0 (mask == NULL: all).
+ * Start/target points are drawn by Philox4x32-10 keyed with `seed`, counter (global env, draw,
+ * episode) under the reference's rejection rules (MUW:127-153); velocities, flags and the three
+ * counters are cleared (MUW:118-123,166-168) and the env's episode index is incremented.
+ * obs (may be NULL) receives the observations of ALL envs, [E*N*10] float32 (MUW:170-172). */
+int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, void *stream);
+
+/* Replaces MultiUAVWorld2D.step (MUW:177-241) incl. UAVAgent.step / finish / uavs_in_range
+ * (AG:23-64) and _get_obs (MUW:60-109) for all E envs in one launch.
+ *   actions  [E*N*2] float32 or float64 (action_dtype), the velocity commands n_action[i]
+ *   evaluate MUW:177 `evaluate` flag (out-of-box no longer terminates, MUW:225)
+ *   obs      [E*N*10] float32    rew [E*N] float32    done [E*N] uint8 (0/1) */
+int uavx_step(uavx_handle *h, const void *actions, int action_dtype, int evaluate, float *obs,
+              float *rew, uint8_t *done, void *stream);
+
+/* K consecutive steps from an action tape [K][E*N*2] in ONE launch (state stays in registers):
+ * obs/rew/done receive tapes [K][...] when tape_out != 0, else only the last step's values.
+ * Same semantics as K calls of uavx_step. */
+int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, int evaluate,
+                int tape_out, float *obs, float *rew, uint8_t *done, void *stream);
+
+/* Replaces MultiUAVWorld2D._get_obs for every agent (MUW:60-109): obs [E*N*10] float32. */
+int uavx_observe(uavx_handle *h, float *obs, void *stream);
+
+/* Read / overwrite the agents' fields and env counters (the reference's callers poke
+ * env.agent_list[i].location etc. directly, test_sac_multi_plot_trajectory.py:43-49). */
+int uavx_get_state(uavx_handle *h, const uavx_state_view *dst, void *stream);
+int uavx_set_state(uavx_handle *h, const uavx_state_view *src, void *stream);
+
+/* Episode metrics of MUW:166-168,209,221,238 as the trainers read them before reset
+ * (test_sac_multi.py:164-165): counters [E*4] uint32 = steps, target_reach_count,
+ * collision_count, episode index. */
+int uavx_get_metrics(uavx_handle *h, uint32_t *counters, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * UAVWorld2D
+ * ------------------------------------------------------------------------------------------- */
+int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offset, int device,
+                   uavx_uw_handle **out);                                       /* UW:14-75 */
+int uavx_uw_destroy(uavx_uw_handle *h);
+const char *uavx_uw_last_error(const uavx_uw_handle *h);
+/* UW:119-135; obs [E*4] float32 of all envs (may be NULL). */
+int uavx_uw_reset(uavx_uw_handle *h, const uint8_t *mask, uint64_t seed, float *obs, void *stream);
+/* UW:137-173; actions [E*2]; obs [E*4] f32, rew [E] f32, done [E] u8, info_distance [E] f32
+ * (UW:114-117, may be NULL). */
+int uavx_uw_step(uavx_uw_handle *h, const void *actions, int action_dtype, float *obs, float *rew,
+                 uint8_t *done, float *info_distance, void *stream);
+int uavx_uw_observe(uavx_uw_handle *h, float *obs, void *stream);               /* UW:77-112 */
+int uavx_uw_get_state(uavx_uw_handle *h, const uavx_uw_state_view *dst, void *stream);
+int uavx_uw_set_state(uavx_uw_handle *h, const uavx_uw_state_view *src, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVX_H */

@@ -1,0 +1,128 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/uavx.h
+declares, host logic (sharding, spaces), and the world_size-2 gloo gather."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gym_uav_collision_avoidance_amd import _lib
+    _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "uavx.h")).read()
+    declared = set(re.findall(r"\b(uavx_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"uavx_handle", "uavx_uw_handle"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert lib.uavx_version() == 1
+    assert lib.uavx_strerror(-1) == b"invalid argument"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gym_uav_collision_avoidance_amd as pkg
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.BatchedMultiUAVWorld2D(4)
+    from gym_uav_collision_avoidance_amd.envs import MultiUAVWorld2D, UAVWorld2D
+    with pytest.raises(RuntimeError):
+        MultiUAVWorld2D()
+    with pytest.raises(RuntimeError):
+        UAVWorld2D()
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "gym_uav_collision_avoidance_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "uavx_oracle" not in txt, f
+
+
+def test_box_space():
+    from gym_uav_collision_avoidance_amd.spaces import Box
+    b = Box(-10.0, 10.0, shape=(2,), dtype=np.float32)
+    np.random.seed(3)
+    s = b.sample()
+    assert s.dtype == np.float32 and s.shape == (2,) and b.contains(s)
+    assert float(np.linalg.norm(b.high)) == pytest.approx(14.142135, rel=1e-6)  # test_sac_multi.py:77
+
+
+def test_shard_range_partitions_exactly():
+    from gym_uav_collision_avoidance_amd.sharding import shard_range
+    for total, world in ((262144, 8), (65536, 1), (10, 3), (7, 8)):
+        spans = [shard_range(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (o1, c1), (o2, _) in zip(spans, spans[1:]):
+            assert o1 + c1 == o2
+
+
+def test_philox_streams_are_keyed_by_global_env(oracle_mod):
+    """Shard independence of reset: resetting global envs [0,12) in one piece equals
+    resetting [0,5) and [5,12) separately with env_offset."""
+    kw = dict(num_agents=4)
+    whole = oracle_mod.OracleMulti(num_envs=12, **kw)
+    whole.reset_philox(42)
+    a = oracle_mod.OracleMulti(num_envs=5, **kw)
+    b = oracle_mod.OracleMulti(num_envs=7, **kw)
+    a.reset_philox(42, env_offset=0)
+    b.reset_philox(42, env_offset=5)
+    np.testing.assert_array_equal(whole.loc, np.concatenate([a.loc, b.loc]))
+    np.testing.assert_array_equal(whole.tgt, np.concatenate([a.tgt, b.tgt]))
+    # Philox4x32-10 known-answer vectors (Random123 kat_vectors)
+    np.testing.assert_array_equal(oracle_mod.philox4x32([0, 0, 0, 0], [0, 0]),
+                                  np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], dtype=np.uint32))
+    np.testing.assert_array_equal(oracle_mod.philox4x32([0xffffffff] * 4, [0xffffffff] * 2),
+                                  np.array([0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd], dtype=np.uint32))
+    np.testing.assert_array_equal(oracle_mod.philox4x32([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]),
+                                  np.array([0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1], dtype=np.uint32))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gather_worker(rank, world, port, total, q):
+    import torch.distributed as dist
+    from gym_uav_collision_avoidance_amd.sharding import gather_episode_metrics, shard_range, summarize_metrics
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    off, cnt = shard_range(total, world, rank)
+    rows = torch.arange(off, off + cnt, dtype=torch.int32)
+    local = torch.stack([rows * 3, rows % 5, rows % 2, torch.ones_like(rows)], dim=1)  # fake counters keyed by global env
+    out = gather_episode_metrics(local, dst=0)
+    if rank == 0:
+        q.put((out.numpy(), summarize_metrics(out, 4)))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_metrics_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, total, world = _free_port(), 11, 2   # uneven shards: 6 + 5
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, summary = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows = np.arange(total)
+    want = np.stack([rows * 3, rows % 5, rows % 2, np.ones_like(rows)], axis=1)
+    np.testing.assert_array_equal(got, want)
+    assert summary["success_rate"] == pytest.approx((rows % 5).sum() / (4 * total))
