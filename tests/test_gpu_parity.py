@@ -27,6 +27,10 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def _ctor(cfg):
+    return {k: v for k, v in cfg.items() if k != "tau"}  # tau is fixed at 0.02 in the ctor (MUW:26)
+
+
 def _check_multi_state(env, ref, ctx, vel_exact=True):
     st = {k: _np(v) for k, v in env.get_state().items()}
     np.testing.assert_array_equal(st["flags"], ref["flags"], err_msg=ctx + " flags")
@@ -45,7 +49,7 @@ def test_multi_fixture_replay(amd, name):
     data, meta = load_fixture(name)
     cfg = meta["cfg"]
     n = cfg["num_agents"]
-    env = amd.BatchedMultiUAVWorld2D(1, **cfg)
+    env = amd.BatchedMultiUAVWorld2D(1, **_ctor(cfg))
     env.set_state(loc=data["init_loc"][None], vel=data["init_vel"][None], tgt=data["init_tgt"][None],
                   init_d=data["init_init_d"][None], prev_d=data["init_prev_d"][None], flags=data["init_flags"][None],
                   counters=np.concatenate([data["init_counters"], [0]])[None])
@@ -75,7 +79,7 @@ def test_multi_circular_fixture_float32_positions(amd, name):
     float32, so positions are compared to float32 resolution and masks must still agree."""
     data, meta = load_fixture(name)
     cfg = meta["cfg"]
-    env = amd.BatchedMultiUAVWorld2D(1, **cfg)
+    env = amd.BatchedMultiUAVWorld2D(1, **_ctor(cfg))
     env.set_state(loc=data["init_loc"][None], vel=data["init_vel"][None], tgt=data["init_tgt"][None],
                   init_d=data["init_init_d"][None], prev_d=data["init_prev_d"][None], flags=data["init_flags"][None])
     mism = 0
