@@ -36,30 +36,36 @@
 
 namespace uavx {
 
+struct Goal { float tx, ty, init_d; };  // 12 B, read-only on the step path (one dwordx3 load)
+
 struct MultiParams {
     double tau, amax, vmax;
     double lox, loy, hix, hiy;
     double speed_sq_lim;  // ‖v‖ < 0.2 (MUW:218)  <=>  fma(vy,vy,vx*vx) < speed_sq_lim
-    float two_r;          // float32(2*collider_radius): np.float32 <= python float compares in f32
-    float d_sense;        // float32(d_sense)
-    float vmax_norm;      // ‖(max_speed,max_speed)‖  MUW:62,183
-    float inv_diag;       // 1/‖(x_size,y_size)‖      MUW:17,68
-    float two_r_reset;    // same threshold, reset rejection (MUW:135,146,151)
+    // exact float32 limits on the SQUARED distance s = fl(dx*dx)+fl(dy*dy) (sqrtf is monotone):
+    float sq_sense;       // sqrtf(s) <  float32(d_sense)   <=>  s <  sq_sense   (AG:52)
+    float sq_two_r;       // sqrtf(s) <= float32(2R)        <=>  s <= sq_two_r   (MUW:203)
+    float sq_hard;        // sqrtf(s) <= 1.0                <=>  s <= sq_hard    (MUW:207)
+    float inv_sense;      // 1/float32(d_sense)             MUW:77
+    float vmax_norm;      // ‖(max_speed,max_speed)‖        MUW:62,183
+    float inv_vmax_norm;
+    float inv_diag;       // 1/‖(x_size,y_size)‖            MUW:17,68
+    float two_r_reset;    // float32(2R), reset rejection (MUW:135,146,151)
     int N, epw, magic;    // agents per env, envs per wave, ceil(65536/N)+... for lane/N
     int64_t E, env_offset;
     float4 *dyn;
     double2 *vel;
-    float *goal;
+    Goal *goal;
     uint32_t *steps, *reach, *coll, *episode;
 };
 
 struct LaneMap {
     int lane, wib;   // lane in wave, wave in block
-    int g, i, base;  // env group within the wave, agent index, first lane of the group
+    int i, base;     // agent index in its env, first lane of the env's group
     bool active;
-    int64_t e, a;    // env, agent slot
-    int64_t a0;      // first agent slot of this wave
-    int cnt;         // active agent slots in this wave (contiguous from a0)
+    uint32_t e, a;   // env, agent slot (E*N < 2^28, checked by uavx_create)
+    uint32_t a0;     // first agent slot of this wave
+    int cnt;         // active agent slots in this wave: lanes [0, cnt), slots [a0, a0 + cnt)
 };
 
 template <int NT>
@@ -69,22 +75,23 @@ __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     const int epw = NT ? (kWave / NT) : p.epw;
     m.lane = threadIdx.x & (kWave - 1);
     m.wib = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + m.wib;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + m.wib;
+    int g;
     if (NT) {
-        m.g = m.lane / NT;
+        g = m.lane / NT;
         m.i = m.lane % NT;
     } else {
-        m.g = (m.lane * p.magic) >> 16;  // floor(lane / N) for lane < 64
-        m.i = m.lane - m.g * N;
+        g = (m.lane * p.magic) >> 16;  // floor(lane / N) for lane < 64
+        m.i = m.lane - g * N;
     }
-    const int64_t e0 = wave * epw;
-    m.e = e0 + m.g;
-    m.active = (m.g < epw) && (m.e < p.E);
-    m.base = m.active ? m.g * N : 0;  // idle lanes still execute the LDS scan: keep it in bounds
-    m.a = m.e * N + m.i;
+    const uint32_t E = (uint32_t)p.E;
+    const uint32_t e0 = wave * epw;
+    const uint32_t envs_here = e0 < E ? min(E - e0, (uint32_t)epw) : 0u;
+    m.e = e0 + g;
+    m.active = (uint32_t)g < envs_here;
+    m.base = m.active ? g * N : 0;  // idle lanes still execute the LDS scan: keep it in bounds
     m.a0 = e0 * N;
-    int64_t envs_here = p.E - e0;
-    envs_here = envs_here < 0 ? 0 : (envs_here > epw ? epw : envs_here);
+    m.a = m.a0 + m.lane;            // whole envs are packed from lane 0: slot = a0 + lane
     m.cnt = (int)envs_here * N;
     return m;
 }
@@ -102,26 +109,33 @@ struct Lds {
     float obs[kWavesPerBlock][kWave * UAVX_OBS_DIM];
 };
 
-__device__ __forceinline__ void load_agent(const MultiParams &p, int64_t a, AgentRegs &s) {
+// Agent slots are addressed with 32-bit lane offsets from scalar base pointers (saddr + voffset
+// addressing; uavx_create rejects E*N >= 2^28).
+__device__ __forceinline__ void load_agent(const MultiParams &p, uint32_t a, AgentRegs &s) {
     const float4 d = p.dyn[a];
     const double2 v = p.vel[a];
     s.x = d.x; s.y = d.y; s.prev_d = d.z; s.flags = __float_as_uint(d.w);
     s.vx = v.x; s.vy = v.y;
-    s.tx = p.goal[3 * a + 0]; s.ty = p.goal[3 * a + 1]; s.init_d = p.goal[3 * a + 2];
+    const Goal g = p.goal[a];
+    s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d;
 }
-__device__ __forceinline__ void store_agent(const MultiParams &p, int64_t a, const AgentRegs &s) {
+__device__ __forceinline__ void store_agent(const MultiParams &p, uint32_t a, const AgentRegs &s) {
     p.dyn[a] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags));
     p.vel[a] = make_double2(s.vx, s.vy);
 }
 
-// Two nearest other agents strictly within d_sense at FINAL positions, ascending, ties -> lower
-// index (AG:44-64 as used by MUW:75-95), plus — when STEP — the minimum in-range distance under the
-// Gauss-Seidel position rule (MUW:198-210 only compares the nearest ones against thresholds, so the
-// minimum decides both tests).
+// Neighbour scan of one agent over the other N-1 agents of its env (positions staged in LDS).
+//  * obs part (AG:44-64 as used by MUW:75-95): the two nearest strictly within d_sense at FINAL
+//    positions, ascending by the float32 distance, ties -> lower index (agents are visited in
+//    ascending index order and only a strictly smaller distance displaces an entry);
+//  * STEP part (MUW:198-210): the reference tests the nearest in-range agents against the thresholds
+//    2R and 1.0, so only the MINIMUM in-range distance under the Gauss-Seidel rule (j<i moved, j>i
+//    not yet) matters.  sqrtf is monotone, so every threshold test is done on the squared distance
+//    fl(dx*dx)+fl(dy*dy) against a host-computed exact float32 limit (no sqrt on this part).
 struct Neigh {
-    float d1, d2, dx1, dy1, dx2, dy2;
+    float d1, d2;
     int j1, j2;
-    float step_min;
+    float step_sq_min;
 };
 
 template <int NT, bool STEP>
@@ -130,62 +144,88 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
     const int N = NT ? NT : p.N;
     Neigh r;
     r.d1 = r.d2 = INFINITY;
-    r.dx1 = r.dy1 = r.dx2 = r.dy2 = 0.f;
     r.j1 = r.j2 = -1;
-    r.step_min = INFINITY;
+    r.step_sq_min = INFINITY;
 #pragma unroll
-    for (int j = 0; j < N; j++) {
+    for (int k = 0; k < N - 1; k++) {
+        const int j = k + (k >= m.i ? 1 : 0);  // ascending over the other agents, self skipped
         const float4 q = lds.pos[m.wib][m.base + j];
         const float dxn = q.z - nx, dyn = q.w - ny;  // target_agent.location - self.location (AG:51)
-        const float dn = norm32(dxn, dyn);
-        const bool other = (j != m.i);
+        const float ax = dxn * dxn, ay = dyn * dyn;
+        const float sn = ax + ay;
         if (STEP) {
-            const float dold = norm32(q.x - nx, q.y - ny);
-            const float ds = (j < m.i) ? dn : dold;  // j<i already moved this step, j>i not yet
-            if (other && ds < p.d_sense) r.step_min = fminf(r.step_min, ds);
+            const float dxo = q.x - nx, dyo = q.y - ny;
+            const float bx = dxo * dxo, by = dyo * dyo;
+            const float so = bx + by;
+            const float ss = (j < m.i) ? sn : so;     // j<i already moved this step, j>i not yet
+            if (ss < p.sq_sense) r.step_sq_min = fminf(r.step_sq_min, ss);
         }
-        if (other && dn < p.d_sense) {  // AG:52
+        if (sn < p.sq_sense) {                         // AG:52  d < d_sense
+            const float dn = sqrtf(sn);                // AG:51  (IEEE-rounded)
             if (dn < r.d1) {
-                r.d2 = r.d1; r.j2 = r.j1; r.dx2 = r.dx1; r.dy2 = r.dy1;
-                r.d1 = dn; r.j1 = j; r.dx1 = dxn; r.dy1 = dyn;
+                r.d2 = r.d1; r.j2 = r.j1;
+                r.d1 = dn; r.j1 = j;
             } else if (dn < r.d2) {
-                r.d2 = dn; r.j2 = j; r.dx2 = dxn; r.dy2 = dyn;
+                r.d2 = dn; r.j2 = j;
             }
         }
     }
     return r;
 }
 
+// atan2f for finite inputs, ~2 ulp: octant reduction + Cephes atanf polynomial on |t| <= tan(pi/8).
+// (Results only feed float32 observation/reward features that are compared at 1e-5.)
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const bool big = mn > 0.41421356237f * mx;
+    const float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    den = (mx == 0.f) ? 1.f : den;              // atan2(0, 0) = 0
+    const float t = num * __builtin_amdgcn_rcpf(den);
+    const float z = t * t;
+    float pl = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    pl = fmaf(pl, z, 1.99777106478e-1f);
+    pl = fmaf(pl, z, -3.33329491539e-1f);
+    float r = fmaf(pl * z, t, t);
+    r = big ? r + 0.78539816339744830962f : r;
+    r = (ay > ax) ? 1.57079632679489661923f - r : r;
+    r = (x < 0.f) ? kPi - r : r;
+    return copysignf(r, y);
+}
+
 // MUW:60-109 in float32 (angles compared on the circle; see DESIGN.md numerics).
 __device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap &m, const Lds &lds, const Neigh &nb,
-                                             float speed, float theta, float dist_t, float dth, float o[10]) {
-    o[0] = speed / p.vmax_norm;      // MUW:62
+                                             float nx, float ny, float speed, float theta, float dist_t, float dth,
+                                             float o[10]) {
+    o[0] = speed * p.inv_vmax_norm;  // MUW:62
     o[1] = theta * kInvPi;           // MUW:64
     o[2] = dist_t * p.inv_diag;      // MUW:68
     o[3] = dth * kInvPi;             // MUW:72
+    // absent neighbour: d=1, bearing (pi + theta) - theta wraps to +-pi -> +-1 (one point on the circle), heading 0
+    o[4] = 1.f; o[5] = 1.f; o[6] = 0.f;
+    o[7] = 1.f; o[8] = 1.f; o[9] = 0.f;
     if (nb.j1 >= 0) {
-        o[4] = nb.d1 / p.d_sense;                                           // MUW:77
-        o[5] = wrap_pi(atan2f(nb.dy1, nb.dx1) - theta) * kInvPi;            // MUW:78-81
-        o[6] = wrap_pi(lds.theta[m.wib][m.base + nb.j1] - theta) * kInvPi;  // MUW:82-85
-    } else {
-        o[4] = 1.f; o[5] = 1.f; o[6] = 0.f;  // (pi + theta) - theta wraps to +-pi -> +-1 (same point)
+        const float4 q = lds.pos[m.wib][m.base + nb.j1];
+        o[4] = nb.d1 * p.inv_sense;                                                 // MUW:77
+        o[5] = wrap_pi(atan2_fast(q.w - ny, q.z - nx) - theta) * kInvPi;            // MUW:78-81
+        o[6] = wrap_pi(lds.theta[m.wib][m.base + nb.j1] - theta) * kInvPi;          // MUW:82-85
     }
     if (nb.j2 >= 0) {
-        o[7] = nb.d2 / p.d_sense;                                           // MUW:87
-        o[8] = wrap_pi(atan2f(nb.dy2, nb.dx2) - theta) * kInvPi;            // MUW:88-91
-        o[9] = wrap_pi(lds.theta[m.wib][m.base + nb.j2] - theta) * kInvPi;  // MUW:92-95
-    } else {
-        o[7] = 1.f; o[8] = 1.f; o[9] = 0.f;
+        const float4 q = lds.pos[m.wib][m.base + nb.j2];
+        o[7] = nb.d2 * p.inv_sense;                                                 // MUW:87
+        o[8] = wrap_pi(atan2_fast(q.w - ny, q.z - nx) - theta) * kInvPi;            // MUW:88-91
+        o[9] = wrap_pi(lds.theta[m.wib][m.base + nb.j2] - theta) * kInvPi;          // MUW:92-95
     }
 }
 
-// Wave-cooperative store of the wave's contiguous obs block: lane-major [64][10] in LDS -> 16-byte
-// (or 8-byte when the block base is only 8-byte aligned) contiguous global stores.
+// Wave-cooperative store of the wave's contiguous obs block (cnt*40 B starting at slot a0): the
+// lane-major [64][10] tile is staged in LDS and written back with lane-contiguous vector stores.
+// Even N: a0 and cnt are even, so the block is 16-byte aligned and a whole number of float4
+// (uavx_create/step check the 16-byte alignment of the caller's obs pointer); otherwise float2.
 template <int NT>
 __device__ __forceinline__ void store_obs_block(const LaneMap &m, Lds &lds, const float o[10], float *obs_out) {
     float *stage = lds.obs[m.wib];
-    // lane k of the wave holds agent slot a0 + (k - idle lanes before it); with whole envs packed
-    // from lane 0 the active lanes are exactly [0, cnt) in slot order.
     if (m.active) {
         float2 *dst = reinterpret_cast<float2 *>(stage + m.lane * UAVX_OBS_DIM);
 #pragma unroll
@@ -193,24 +233,18 @@ __device__ __forceinline__ void store_obs_block(const LaneMap &m, Lds &lds, cons
     }
     wave_lds_sync();
     const int nfloat = m.cnt * UAVX_OBS_DIM;
-    float *gbase = obs_out + m.a0 * UAVX_OBS_DIM;
-    // wave-uniform: the block base a0*40 B is 16-byte aligned unless a0 is odd (odd N) or the tape offset is
-    const bool vec4 = (reinterpret_cast<uintptr_t>(gbase) & 15u) == 0;
-    if (vec4) {
+    float *gbase = obs_out + (size_t)m.a0 * UAVX_OBS_DIM;
+    if (NT != 0 && NT % 2 == 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int f = (k * kWave + m.lane) * 4;
-            if (f + 3 < nfloat) {
-                *reinterpret_cast<float4 *>(gbase + f) = *reinterpret_cast<const float4 *>(stage + f);
-            } else {
-                for (int t = f; t < nfloat && t < f + 4; t++) gbase[t] = stage[t];
-            }
+            if (f < nfloat) *reinterpret_cast<float4 *>(gbase + f) = *reinterpret_cast<const float4 *>(stage + f);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int f = (k * kWave + m.lane) * 2;
-            if (f + 1 < nfloat) *reinterpret_cast<float2 *>(gbase + f) = *reinterpret_cast<const float2 *>(stage + f);
+            if (f < nfloat) *reinterpret_cast<float2 *>(gbase + f) = *reinterpret_cast<const float2 *>(stage + f);
         }
     }
     wave_lds_sync();
@@ -233,8 +267,8 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     const float dist_t = norm32(tdx, tdy);                   // AG:33 / MUW:67
     if (!was_done) d = dist_t;
     // heading; finish() only rescales the velocity (AG:40), so one atan2 serves reward and obs
-    const float theta = atan2f((float)s.vy, (float)s.vx);    // MUW:63,185
-    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);     // MUW:184-186 == MUW:69-71
+    const float theta = atan2_fast((float)s.vy, (float)s.vx);   // MUW:63,185
+    const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);    // MUW:184-186 == MUW:69-71
 
     if (m.active) {
         lds.pos[m.wib][m.lane] = make_float4(ox, oy, s.x, s.y);
@@ -243,25 +277,26 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     wave_lds_sync();
     const Neigh nb = scan_neighbours<NT, true>(p, m, lds, s.x, s.y);
 
-    // reward shaping, MUW:188-195 (float32; |error| << 1e-5)
-    float r = -0.01f * fminf(p.vmax_norm / s.init_d, 1.0f);  // MUW:189
-    r += 50.0f * ((pd - d) / p.vmax_norm);                   // MUW:190 (pd - d is a float32 subtraction there too)
-    const float frac = d / (1.5f * s.init_d);                // MUW:192,194
+    // reward shaping, MUW:188-195 (float32, reciprocals instead of divisions; |error| << 1e-5)
+    const float inv_init = __builtin_amdgcn_rcpf(s.init_d);
+    float r = -0.01f * fminf(p.vmax_norm * inv_init, 1.0f);  // MUW:189
+    r += (50.0f * p.inv_vmax_norm) * (pd - d);               // MUW:190 (pd - d is a float32 subtraction there too)
+    const float frac = d * inv_init * (1.0f / 1.5f);         // MUW:192,194
     r *= (r > 0.f) ? (1.0f - frac) : (1.0f + frac);
     r -= 0.01f * fabsf(dth);                                 // MUW:195
 
-    // collisions, MUW:197-210
-    const bool collision = nb.step_min <= p.two_r;           // MUW:203
+    // collisions, MUW:197-210 (exact threshold tests on the squared distance)
+    const bool collision = nb.step_sq_min <= p.sq_two_r;     // MUW:203  dist <= 2R
     if (collision) r = -2.0f;                                // MUW:204
     coll_ev = 0;
-    if (nb.step_min <= 1.0f && !(s.flags & (UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED))) {  // MUW:207-208
+    if (nb.step_sq_min <= p.sq_hard && !(s.flags & (UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED))) {  // MUW:207-208
         coll_ev = 1;                                         // MUW:209
         s.flags |= UAVX_FLAG_COLLIDED;                       // MUW:210
     }
     // termination, MUW:213-227
     const double sq = fma(s.vy, s.vy, s.vx * s.vx);          // MUW:214 (np.linalg.norm's float64 dot)
     const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);
-    float speed = sqrtf((float)sq);
+    float speed = __builtin_amdgcn_sqrtf((float)sq);         // obs feature only
     reach_ev = 0;
     if (d < 0.5f && !collision && sq < p.speed_sq_lim) {     // MUW:218
         done_out = 1;
@@ -271,7 +306,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
         double fx = s.vx / nv * 0.001, fy = s.vy / nv * 0.001;
         if (fx != fx || fy != fy) { fx = 0.0; fy = 0.0; }    // AG:41-42
         s.vx = fx; s.vy = fy;
-        speed = sqrtf((float)fma(fy, fy, fx * fx));
+        speed = __builtin_amdgcn_sqrtf((float)fma(fy, fy, fx * fx));
         r += 10.0f;                                          // MUW:223
     } else if (oob) {
         done_out = evaluate ? 0u : 1u;                       // MUW:224-225
@@ -280,41 +315,74 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     }
     s.prev_d = d;                                            // MUW:229
     rew = r;
-    assemble_obs(p, m, lds, nb, speed, theta, dist_t, dth, o);  // MUW:233-235
+    assemble_obs(p, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);  // MUW:233-235
 }
 
+template <bool ACT64>
+__device__ __forceinline__ void load_action(const void *__restrict__ actions, uint32_t a, double &ax, double &ay) {
+    if (ACT64) {
+        const double2 v = reinterpret_cast<const double2 *>(actions)[a];
+        ax = v.x; ay = v.y;
+    } else {
+        const float2 v = reinterpret_cast<const float2 *>(actions)[a];
+        ax = (double)v.x; ay = (double)v.y;
+    }
+}
+
+// One env step per launch (the RL loop's shape: the policy runs between two launches).
 template <int NT, bool ACT64>
 __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
-                                                      int K, int tape_out, float *__restrict__ obs_out,
-                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
+                                                      float *__restrict__ obs_out, float *__restrict__ rew_out,
+                                                      uint8_t *__restrict__ done_out) {
+    __shared__ Lds lds;
+    const LaneMap m = lane_map<NT>(p);
+    AgentRegs s = {};
+    double ax = 0.0, ay = 0.0;
+    if (m.active) {
+        load_agent(p, m.a, s);
+        load_action<ACT64>(actions, m.a, ax, ay);
+    }
+    float o[10], rew;
+    uint32_t dn, re, ce;
+    step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
+    if (m.active) {
+        store_agent(p, m.a, s);
+        rew_out[m.a] = rew;
+        done_out[m.a] = (uint8_t)dn;
+        if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
+        if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
+        if (m.i == 0) atomicAdd(&p.steps[m.e], 1u);          // MUW:238 (no-return atomic: nothing waits on it)
+    }
+    store_obs_block<NT>(m, lds, o, obs_out);
+}
+
+// K consecutive steps per launch from an action tape (open-loop rollouts): agent state stays in
+// registers, only actions are read and obs/rew/done written per step.
+template <int NT, bool ACT64>
+__global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+                                                        int K, int tape_out, float *__restrict__ obs_out,
+                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     __shared__ Lds lds;
     const int N = NT ? NT : p.N;
     const LaneMap m = lane_map<NT>(p);
     AgentRegs s = {};
     if (m.active) load_agent(p, m.a, s);
-    const int64_t A = p.E * N;
+    const size_t A = (size_t)p.E * N;
     uint32_t reach_acc = 0, coll_acc = 0;
     for (int k = 0; k < K; k++) {
         double ax = 0.0, ay = 0.0;
-        if (m.active) {
-            if (ACT64) {
-                const double2 a = reinterpret_cast<const double2 *>(actions)[k * A + m.a];
-                ax = a.x; ay = a.y;
-            } else {
-                const float2 a = reinterpret_cast<const float2 *>(actions)[k * A + m.a];
-                ax = (double)a.x; ay = (double)a.y;
-            }
-        }
+        const size_t abytes = (ACT64 ? 16 : 8) * A * k;
+        if (m.active) load_action<ACT64>(reinterpret_cast<const char *>(actions) + abytes, m.a, ax, ay);
         float o[10], rew;
         uint32_t dn, re, ce;
         step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
         reach_acc += re;
         coll_acc += ce;
         if (tape_out || k == K - 1) {
-            const int64_t off = tape_out ? (int64_t)k * A : 0;
+            const size_t off = tape_out ? (size_t)k * A : 0;
             if (m.active) {
-                rew_out[off + m.a] = rew;
-                done_out[off + m.a] = (uint8_t)dn;
+                (rew_out + off)[m.a] = rew;
+                (done_out + off)[m.a] = (uint8_t)dn;
             }
             store_obs_block<NT>(m, lds, o, obs_out + off * UAVX_OBS_DIM);
         } else {
@@ -325,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
         store_agent(p, m.a, s);
         if (reach_acc) atomicAdd(&p.reach[m.e], reach_acc);  // MUW:221
         if (coll_acc) atomicAdd(&p.coll[m.e], coll_acc);     // MUW:209
-        if (m.i == 0) p.steps[m.e] += (uint32_t)K;           // MUW:238
+        if (m.i == 0) atomicAdd(&p.steps[m.e], (uint32_t)K); // MUW:238
     }
 }
 
@@ -337,17 +405,17 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *_
     if (m.active) load_agent(p, m.a, s);
     const float tdx = s.tx - s.x, tdy = s.ty - s.y;
     const float dist_t = norm32(tdx, tdy);
-    const float theta = atan2f((float)s.vy, (float)s.vx);
-    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);
+    const float theta = atan2_fast((float)s.vy, (float)s.vx);
+    const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);
     if (m.active) {
         lds.pos[m.wib][m.lane] = make_float4(s.x, s.y, s.x, s.y);
         lds.theta[m.wib][m.lane] = theta;
     }
     wave_lds_sync();
     const Neigh nb = scan_neighbours<NT, false>(p, m, lds, s.x, s.y);
-    const float speed = sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
+    const float speed = __builtin_amdgcn_sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
     float o[10];
-    assemble_obs(p, m, lds, nb, speed, theta, dist_t, dth, o);
+    assemble_obs(p, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);
     store_obs_block<NT>(m, lds, o, obs_out);
 }
 
@@ -361,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
     const uint64_t ge = (uint64_t)(p.env_offset + e);
     PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[e], (uint32_t)seed, (uint32_t)(seed >> 32), 0u};
     float4 *dyn = p.dyn + e * N;
-    float *goal = p.goal + 3 * e * N;
+    Goal *goal = p.goal + e * N;
     for (int i = 0; i < N; i++) {  // MUW:126-137
         float x, y;
         bool replicated = true;
@@ -384,11 +452,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
             rng.point32(p.lox, p.loy, p.hix, p.hiy, tx, ty);
             replicated = norm32(tx - me.x, ty - me.y) <= p.two_r_reset;  // MUW:146
             for (int j = 0; j < i && !replicated; j++) {
-                if (norm32(goal[3 * j] - tx, goal[3 * j + 1] - ty) <= p.two_r_reset) replicated = true;  // MUW:151
+                if (norm32(goal[j].tx - tx, goal[j].ty - ty) <= p.two_r_reset) replicated = true;  // MUW:151
             }
         }
         const float d0 = norm32(tx - me.x, ty - me.y);  // MUW:154
-        goal[3 * i] = tx; goal[3 * i + 1] = ty; goal[3 * i + 2] = d0;
+        goal[i] = Goal{tx, ty, d0};
         dyn[i] = make_float4(me.x, me.y, d0, __uint_as_float(0u));  // MUW:155 prev_distance = init_distance
     }
     p.steps[e] = 0; p.reach[e] = 0; p.coll[e] = 0;  // MUW:166-168
@@ -404,8 +472,8 @@ __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_s
         if (v.prev_d) v.prev_d[a] = d.z;
         if (v.flags) v.flags[a] = (uint8_t)__float_as_uint(d.w);
         if (v.vel) { const double2 w = p.vel[a]; v.vel[2 * a] = w.x; v.vel[2 * a + 1] = w.y; }
-        if (v.tgt) { v.tgt[2 * a] = p.goal[3 * a]; v.tgt[2 * a + 1] = p.goal[3 * a + 1]; }
-        if (v.init_d) v.init_d[a] = p.goal[3 * a + 2];
+        if (v.tgt) { v.tgt[2 * a] = p.goal[a].tx; v.tgt[2 * a + 1] = p.goal[a].ty; }
+        if (v.init_d) v.init_d[a] = p.goal[a].init_d;
     }
     if (a < p.E && v.counters) {
         v.counters[4 * a + 0] = p.steps[a]; v.counters[4 * a + 1] = p.reach[a];
@@ -423,8 +491,8 @@ __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_s
         if (v.flags) d.w = __uint_as_float((uint32_t)v.flags[a]);
         p.dyn[a] = d;
         if (v.vel) p.vel[a] = make_double2(v.vel[2 * a], v.vel[2 * a + 1]);
-        if (v.tgt) { p.goal[3 * a] = v.tgt[2 * a]; p.goal[3 * a + 1] = v.tgt[2 * a + 1]; }
-        if (v.init_d) p.goal[3 * a + 2] = v.init_d[a];
+        if (v.tgt) { p.goal[a].tx = v.tgt[2 * a]; p.goal[a].ty = v.tgt[2 * a + 1]; }
+        if (v.init_d) p.goal[a].init_d = v.init_d[a];
     }
     if (a < p.E && v.counters) {
         p.steps[a] = v.counters[4 * a + 0]; p.reach[a] = v.counters[4 * a + 1];
@@ -471,18 +539,39 @@ double sq_threshold(double lim) {
     return s;
 }
 
+// float32 limits for threshold tests on squared distances (host sqrtf is correctly rounded):
+// smallest s with sqrtf(s) >= lim   ->   sqrtf(s) <  lim  <=>  s <  result
+float sq_limit_lt(float lim) {
+    float s = lim * lim;
+    while (s > 0.f && std::sqrt(s) >= lim) s = std::nextafterf(s, 0.f);
+    while (std::sqrt(s) < lim) s = std::nextafterf(s, INFINITY);
+    return s;
+}
+// largest s with sqrtf(s) <= lim    ->   sqrtf(s) <= lim  <=>  s <= result
+float sq_limit_le(float lim) {
+    float s = lim * lim;
+    while (std::sqrt(s) <= lim) s = std::nextafterf(s, INFINITY);
+    while (s > 0.f && std::sqrt(s) > lim) s = std::nextafterf(s, 0.f);
+    return s;
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <int NT>
-int launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actions, int action_dtype, int evaluate, int K,
-                   int tape_out, float *obs, float *rew, uint8_t *done) {
-    if (action_dtype == UAVX_F64)
-        hipLaunchKernelGGL((step_kernel<NT, true>), grid, dim3(kBlock), 0, st, h->p, actions, evaluate, K, tape_out, obs,
-                           rew, done);
-    else
-        hipLaunchKernelGGL((step_kernel<NT, false>), grid, dim3(kBlock), 0, st, h->p, actions, evaluate, K, tape_out, obs,
-                           rew, done);
-    return 0;
+void launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actions, int action_dtype, int evaluate, int K,
+                    int tape_out, float *obs, float *rew, uint8_t *done) {
+    const dim3 blk(kBlock);
+    if (K == 1) {
+        if (action_dtype == UAVX_F64)
+            hipLaunchKernelGGL((step_kernel<NT, true>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+        else
+            hipLaunchKernelGGL((step_kernel<NT, false>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+    } else {
+        if (action_dtype == UAVX_F64)
+            hipLaunchKernelGGL((step_k_kernel<NT, true>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
+        else
+            hipLaunchKernelGGL((step_k_kernel<NT, false>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
+    }
 }
 
 dim3 wave_grid(const uavx_handle *h) {
@@ -527,6 +616,7 @@ const char *uavx_strerror(int status) {
 int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device, uavx_handle **out) {
     if (!cfg || !out || num_envs <= 0 || env_offset < 0) return UAVX_ERR_INVALID_ARG;
     if (cfg->num_agents < 1 || cfg->num_agents > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
+    if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 28)) return UAVX_ERR_UNSUPPORTED;  // 32-bit lane offsets
     if (!(cfg->tau > 0) || !(cfg->max_speed > 0) || !(cfg->max_acceleration > 0) || !(cfg->x_size > 0) ||
         !(cfg->y_size > 0) || !(cfg->d_sense > 0) || !(cfg->collider_radius >= 0))
         return UAVX_ERR_INVALID_ARG;
@@ -545,10 +635,13 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
     p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
     p.speed_sq_lim = sq_threshold(0.2);
-    p.two_r = (float)(2 * cfg->collider_radius);
-    p.two_r_reset = p.two_r;
-    p.d_sense = (float)cfg->d_sense;
+    p.two_r_reset = (float)(2 * cfg->collider_radius);
+    p.sq_sense = sq_limit_lt((float)cfg->d_sense);
+    p.sq_two_r = sq_limit_le(p.two_r_reset);
+    p.sq_hard = sq_limit_le(1.0f);  // 2 * HARD_COLLISION_RADIUS, MUW:8,207
+    p.inv_sense = 1.0f / (float)cfg->d_sense;
     p.vmax_norm = (float)std::sqrt(std::fma(cfg->max_speed, cfg->max_speed, cfg->max_speed * cfg->max_speed));
+    p.inv_vmax_norm = 1.0f / p.vmax_norm;
     p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
     p.N = N;
     p.epw = kWave / N;
@@ -575,7 +668,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     char *b = static_cast<char *>(h->slab);
     p.dyn = reinterpret_cast<float4 *>(b + o_dyn);
     p.vel = reinterpret_cast<double2 *>(b + o_vel);
-    p.goal = reinterpret_cast<float *>(b + o_goal);
+    p.goal = reinterpret_cast<Goal *>(b + o_goal);
     p.steps = reinterpret_cast<uint32_t *>(b + o_steps);
     p.reach = reinterpret_cast<uint32_t *>(b + o_reach);
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
@@ -613,7 +706,8 @@ static int launch_observe(uavx_handle *h, float *obs, hipStream_t st) {
 
 int uavx_observe(uavx_handle *h, float *obs, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;
-    if (!obs) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_observe: obs is NULL");
+    if (!obs || (reinterpret_cast<uintptr_t>(obs) & 15u))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_observe: obs is NULL or not 16-byte aligned");
     UAVX_ENTER(h);
     return launch_observe(h, obs, static_cast<hipStream_t>(stream));
 }
@@ -621,6 +715,8 @@ int uavx_observe(uavx_handle *h, float *obs, void *stream) {
 int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;
     UAVX_ENTER(h);
+    if (obs && (reinterpret_cast<uintptr_t>(obs) & 15u))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_reset: obs not 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((h->p.E + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(reset_kernel, grid, dim3(kBlock), 0, st, h->p, mask, seed);
@@ -636,6 +732,9 @@ int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, in
     if (k < 1) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_k: k < 1");
     if (action_dtype != UAVX_F32 && action_dtype != UAVX_F64)
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: action_dtype must be UAVX_F32 or UAVX_F64");
+    if ((reinterpret_cast<uintptr_t>(obs) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) ||
+        (reinterpret_cast<uintptr_t>(rew) & 3u))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: obs/actions must be 16-byte aligned, rew 4-byte aligned");
     UAVX_ENTER(h);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
