@@ -31,6 +31,22 @@ def algorithmic_bytes_per_env_step(n_agents):
     return 107 * n_agents + 24
 
 
+def measured_traffic(E, N):
+    """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
+    produced by tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of this
+    command, with the gfx950 FETCH_SIZE x2 correction).  Only valid for the profiled grid."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("_meta", {}).get("grid") == E * N and "hbm_traffic_bytes_per_launch" in d:
+            best = (d["hbm_traffic_bytes_per_launch"]["total"], os.path.basename(f))
+    return best
+
+
 def polar_actions(gen, shape, vmax_norm, device):
     """a ~ U(-1,1)^2 mapped like the trainers do (test_sac_multi.py:77-80)."""
     a = torch.rand(shape + (2,), generator=gen, device=device) * 2 - 1
@@ -165,6 +181,7 @@ def main():
         kernel_s = dev_ms * 1e-3 / K  # average per-step device time over the timed region
         achieved = bytes_per_launch / kernel_s / 1e9
         summ = summarize_metrics(gathered, N)
+        traffic = measured_traffic(E, N)
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -173,7 +190,8 @@ def main():
                                    f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={args.mode}",
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-index shard x{world}", "mode": args.mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
                          "kernel": "uavx::step_kernel<4,false>"},
             "episode_metrics": summ,

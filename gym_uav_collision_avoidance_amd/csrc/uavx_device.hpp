@@ -24,6 +24,33 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Write-through (sc1) vector stores.  A kernel boundary writes back whatever the launch left dirty
+// in the XCD L2s (MI355X_MICROARCH.md price list, row "boundary": + B / 6 TB/s); the step kernel
+// dirties ~20 MB per launch, so its bulk outputs are stored write-through and drain while the other
+// waves still compute instead of serialising behind the last wave.  Out-of-range offsets are dropped
+// by the buffer bounds check.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kAuxSc1 = 16;  // gfx940+ cache-policy bit SC1 (write-through to memory)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void store16_wt(rsrc_t r, uint32_t byte_off, float4 v) {
+    u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, kAuxSc1);
+}
+__device__ __forceinline__ void store16_wt(rsrc_t r, uint32_t byte_off, double2 v) {
+    const unsigned long long a = __double_as_longlong(v.x), b = __double_as_longlong(v.y);
+    u32x4 d = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, kAuxSc1);
+}
+__device__ __forceinline__ void store8_wt(rsrc_t r, uint32_t byte_off, float2 v) {
+    u32x2 d = {__float_as_uint(v.x), __float_as_uint(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)byte_off, 0, kAuxSc1);
+}
+
 // np.linalg.norm on a float32 pair: fl(fl(x*x) + fl(y*y)) then correctly rounded sqrt (AG:33,51).
 __device__ __forceinline__ float norm32(float x, float y) {
     float a = x * x;

@@ -63,7 +63,7 @@ struct LaneMap {
     int lane, wib;   // lane in wave, wave in block
     int i, base;     // agent index in its env, first lane of the env's group
     bool active;
-    uint32_t e, a;   // env, agent slot (E*N < 2^28, checked by uavx_create)
+    uint32_t e, a;   // env, agent slot (E*N < 2^26, checked by uavx_create)
     uint32_t a0;     // first agent slot of this wave
     int cnt;         // active agent slots in this wave: lanes [0, cnt), slots [a0, a0 + cnt)
 };
@@ -110,7 +110,7 @@ struct Lds {
 };
 
 // Agent slots are addressed with 32-bit lane offsets from scalar base pointers (saddr + voffset
-// addressing; uavx_create rejects E*N >= 2^28).
+// addressing; uavx_create rejects E*N >= 2^26).
 __device__ __forceinline__ void load_agent(const MultiParams &p, uint32_t a, AgentRegs &s) {
     const float4 d = p.dyn[a];
     const double2 v = p.vel[a];
@@ -120,8 +120,17 @@ __device__ __forceinline__ void load_agent(const MultiParams &p, uint32_t a, Age
     s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d;
 }
 __device__ __forceinline__ void store_agent(const MultiParams &p, uint32_t a, const AgentRegs &s) {
+#ifndef UAVX_STATE_WT
+#define UAVX_STATE_WT 0  // A/B on MI355X (65536x4): plain state stores keep dyn/vel in the XCD L2 for the next step: 6.76 vs 7.3 us
+#endif
+#if UAVX_STATE_WT
+    const uint32_t bytes = (uint32_t)p.E * (uint32_t)p.N * 16u;  // dyn and vel are both 16 B per agent
+    store16_wt(make_rsrc(p.dyn, bytes), a * 16u, make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags)));
+    store16_wt(make_rsrc(p.vel, bytes), a * 16u, make_double2(s.vx, s.vy));
+#else
     p.dyn[a] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags));
     p.vel[a] = make_double2(s.vx, s.vy);
+#endif
 }
 
 // Neighbour scan of one agent over the other N-1 agents of its env (positions staged in LDS).
@@ -224,7 +233,8 @@ __device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap
 // Even N: a0 and cnt are even, so the block is 16-byte aligned and a whole number of float4
 // (uavx_create/step check the 16-byte alignment of the caller's obs pointer); otherwise float2.
 template <int NT>
-__device__ __forceinline__ void store_obs_block(const LaneMap &m, Lds &lds, const float o[10], float *obs_out) {
+__device__ __forceinline__ void store_obs_block(const MultiParams &p, const LaneMap &m, Lds &lds, const float o[10],
+                                                float *obs_out) {
     float *stage = lds.obs[m.wib];
     if (m.active) {
         float2 *dst = reinterpret_cast<float2 *>(stage + m.lane * UAVX_OBS_DIM);
@@ -233,18 +243,19 @@ __device__ __forceinline__ void store_obs_block(const LaneMap &m, Lds &lds, cons
     }
     wave_lds_sync();
     const int nfloat = m.cnt * UAVX_OBS_DIM;
-    float *gbase = obs_out + (size_t)m.a0 * UAVX_OBS_DIM;
+    const rsrc_t r = make_rsrc(obs_out, (uint32_t)p.E * (uint32_t)p.N * (UAVX_OBS_DIM * 4u));
+    const uint32_t gbase = m.a0 * (UAVX_OBS_DIM * 4u);  // byte offset of the wave's block
     if (NT != 0 && NT % 2 == 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int f = (k * kWave + m.lane) * 4;
-            if (f < nfloat) *reinterpret_cast<float4 *>(gbase + f) = *reinterpret_cast<const float4 *>(stage + f);
+            if (f < nfloat) store16_wt(r, gbase + f * 4u, *reinterpret_cast<const float4 *>(stage + f));
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int f = (k * kWave + m.lane) * 2;
-            if (f < nfloat) *reinterpret_cast<float2 *>(gbase + f) = *reinterpret_cast<const float2 *>(stage + f);
+            if (f < nfloat) store8_wt(r, gbase + f * 4u, *reinterpret_cast<const float2 *>(stage + f));
         }
     }
     wave_lds_sync();
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
         if (m.i == 0) atomicAdd(&p.steps[m.e], 1u);          // MUW:238 (no-return atomic: nothing waits on it)
     }
-    store_obs_block<NT>(m, lds, o, obs_out);
+    store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
 // K consecutive steps per launch from an action tape (open-loop rollouts): agent state stays in
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
                 (rew_out + off)[m.a] = rew;
                 (done_out + off)[m.a] = (uint8_t)dn;
             }
-            store_obs_block<NT>(m, lds, o, obs_out + off * UAVX_OBS_DIM);
+            store_obs_block<NT>(p, m, lds, o, obs_out + off * UAVX_OBS_DIM);
         } else {
             wave_lds_sync();
         }
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *_
     const float speed = __builtin_amdgcn_sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
     float o[10];
     assemble_obs(p, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);
-    store_obs_block<NT>(m, lds, o, obs_out);
+    store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
 // MUW:116-168 — one lane per env (the rejection loops are sequential inside an env and reset is off
@@ -616,7 +627,7 @@ const char *uavx_strerror(int status) {
 int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device, uavx_handle **out) {
     if (!cfg || !out || num_envs <= 0 || env_offset < 0) return UAVX_ERR_INVALID_ARG;
     if (cfg->num_agents < 1 || cfg->num_agents > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
-    if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 28)) return UAVX_ERR_UNSUPPORTED;  // 32-bit lane offsets
+    if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 26)) return UAVX_ERR_UNSUPPORTED;  // 32-bit byte offsets (obs: 40 B/agent)
     if (!(cfg->tau > 0) || !(cfg->max_speed > 0) || !(cfg->max_acceleration > 0) || !(cfg->x_size > 0) ||
         !(cfg->y_size > 0) || !(cfg->d_sense > 0) || !(cfg->collider_radius >= 0))
         return UAVX_ERR_INVALID_ARG;
