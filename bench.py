@@ -108,13 +108,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X; there is no CPU fallback for the env step path")
+    # UAVX_REHEARSAL=1: several ranks share GPU 0 and talk over gloo (to rehearse the N>1 launch contract on
+    # a one-GPU box; RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("UAVX_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D
     from gym_uav_collision_avoidance_amd.sharding import gather_episode_metrics, summarize_metrics
@@ -151,6 +159,8 @@ def main():
                 env.step(ring[i % R])
 
     run(W)
+    if distributed:
+        gather_episode_metrics(env.metrics(), dst=0)  # communicator / buffers set up outside the timed region
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -170,7 +180,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
 
     if distributed:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 

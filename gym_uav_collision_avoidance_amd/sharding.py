@@ -26,6 +26,8 @@ def gather_episode_metrics(local, dst=0, group=None):
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        local = local.cpu()  # rehearsal backend: gloo gathers host tensors
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
