@@ -39,7 +39,7 @@ namespace uavx {
 struct Goal { float tx, ty, init_d; };  // 12 B, read-only on the step path (one dwordx3 load)
 
 struct MultiParams {
-    double tau, amax, vmax;
+    double tau, rtau, amax, vmax;  // rtau = RN(1/tau), see div_tau()
     double lox, loy, hix, hiy;
     double speed_sq_lim;  // ‖v‖ < 0.2 (MUW:218)  <=>  fma(vy,vy,vx*vx) < speed_sq_lim
     // exact float32 limits on the SQUARED distance s = fl(dx*dx)+fl(dy*dy) (sqrtf is monotone):
@@ -51,6 +51,7 @@ struct MultiParams {
     float inv_vmax_norm;
     float inv_diag;       // 1/‖(x_size,y_size)‖            MUW:17,68
     float two_r_reset;    // float32(2R), reset rejection (MUW:135,146,151)
+    int recip_ok;         // div_tau() may use the reciprocal form for this tau
     int N, epw, magic;    // agents per env, envs per wave, ceil(65536/N)+... for lane/N
     int64_t E, env_offset;
     float4 *dyn;
@@ -155,10 +156,9 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
     r.d1 = r.d2 = INFINITY;
     r.j1 = r.j2 = -1;
     r.step_sq_min = INFINITY;
-#pragma unroll
-    for (int k = 0; k < N - 1; k++) {
-        const int j = k + (k >= m.i ? 1 : 0);  // ascending over the other agents, self skipped
-        const float4 q = lds.pos[m.wib][m.base + j];
+    const float4 *row = &lds.pos[m.wib][m.base];
+    // Branch-free: out-of-range agents enter the insertion with distance +inf, which never displaces.
+    auto visit = [&](int j, float4 q) {
         const float dxn = q.z - nx, dyn = q.w - ny;  // target_agent.location - self.location (AG:51)
         const float ax = dxn * dxn, ay = dyn * dyn;
         const float sn = ax + ay;
@@ -166,17 +166,32 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
             const float dxo = q.x - nx, dyo = q.y - ny;
             const float bx = dxo * dxo, by = dyo * dyo;
             const float so = bx + by;
-            const float ss = (j < m.i) ? sn : so;     // j<i already moved this step, j>i not yet
-            if (ss < p.sq_sense) r.step_sq_min = fminf(r.step_sq_min, ss);
+            const float ss = (j < m.i) ? sn : so;      // j<i already moved this step, j>i not yet
+            r.step_sq_min = fminf(r.step_sq_min, (ss < p.sq_sense) ? ss : INFINITY);
         }
-        if (sn < p.sq_sense) {                         // AG:52  d < d_sense
-            const float dn = sqrtf(sn);                // AG:51  (IEEE-rounded)
-            if (dn < r.d1) {
-                r.d2 = r.d1; r.j2 = r.j1;
-                r.d1 = dn; r.j1 = j;
-            } else if (dn < r.d2) {
-                r.d2 = dn; r.j2 = j;
-            }
+        const float dn = (sn < p.sq_sense) ? sqrtf(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
+        const bool lt1 = dn < r.d1, lt2 = dn < r.d2;
+        r.d2 = lt1 ? r.d1 : (lt2 ? dn : r.d2);
+        r.j2 = lt1 ? r.j1 : (lt2 ? j : r.j2);
+        r.d1 = lt1 ? dn : r.d1;
+        r.j1 = lt1 ? j : r.j1;
+    };
+    if (NT) {
+        // all N-1 LDS reads are issued before the first use (one lgkmcnt wait instead of N-1)
+        constexpr int M = NT > 1 ? NT - 1 : 1;
+        float4 q[M];
+        int js[M];
+#pragma unroll
+        for (int k = 0; k < NT - 1; k++) {
+            js[k] = k + (k >= m.i ? 1 : 0);  // ascending over the other agents, self skipped
+            q[k] = row[js[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < NT - 1; k++) visit(js[k], q[k]);
+    } else {
+        for (int k = 0; k < N - 1; k++) {
+            const int j = k + (k >= m.i ? 1 : 0);
+            visit(j, row[j]);
         }
     }
     return r;
@@ -212,20 +227,20 @@ __device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap
     o[2] = dist_t * p.inv_diag;      // MUW:68
     o[3] = dth * kInvPi;             // MUW:72
     // absent neighbour: d=1, bearing (pi + theta) - theta wraps to +-pi -> +-1 (one point on the circle), heading 0
-    o[4] = 1.f; o[5] = 1.f; o[6] = 0.f;
-    o[7] = 1.f; o[8] = 1.f; o[9] = 0.f;
-    if (nb.j1 >= 0) {
-        const float4 q = lds.pos[m.wib][m.base + nb.j1];
-        o[4] = nb.d1 * p.inv_sense;                                                 // MUW:77
-        o[5] = wrap_pi(atan2_fast(q.w - ny, q.z - nx) - theta) * kInvPi;            // MUW:78-81
-        o[6] = wrap_pi(lds.theta[m.wib][m.base + nb.j1] - theta) * kInvPi;          // MUW:82-85
-    }
-    if (nb.j2 >= 0) {
-        const float4 q = lds.pos[m.wib][m.base + nb.j2];
-        o[7] = nb.d2 * p.inv_sense;                                                 // MUW:87
-        o[8] = wrap_pi(atan2_fast(q.w - ny, q.z - nx) - theta) * kInvPi;            // MUW:88-91
-        o[9] = wrap_pi(lds.theta[m.wib][m.base + nb.j2] - theta) * kInvPi;          // MUW:92-95
-    }
+    const bool has1 = nb.j1 >= 0, has2 = nb.j2 >= 0;
+    const int i1 = m.base + (has1 ? nb.j1 : 0), i2 = m.base + (has2 ? nb.j2 : 0);
+    const float4 q1 = lds.pos[m.wib][i1], q2 = lds.pos[m.wib][i2];
+    const float t1 = lds.theta[m.wib][i1], t2 = lds.theta[m.wib][i2];
+    const float b1 = wrap_pi(atan2_fast(q1.w - ny, q1.z - nx) - theta) * kInvPi;  // MUW:78-81
+    const float b2 = wrap_pi(atan2_fast(q2.w - ny, q2.z - nx) - theta) * kInvPi;  // MUW:88-91
+    const float h1 = wrap_pi(t1 - theta) * kInvPi;                                // MUW:82-85
+    const float h2 = wrap_pi(t2 - theta) * kInvPi;                                // MUW:92-95
+    o[4] = has1 ? nb.d1 * p.inv_sense : 1.f;                                      // MUW:77
+    o[5] = has1 ? b1 : 1.f;
+    o[6] = has1 ? h1 : 0.f;
+    o[7] = has2 ? nb.d2 * p.inv_sense : 1.f;                                      // MUW:87
+    o[8] = has2 ? b2 : 1.f;
+    o[9] = has2 ? h2 : 0.f;
 }
 
 // Wave-cooperative store of the wave's contiguous obs block (cnt*40 B starting at slot a0): the
@@ -270,8 +285,8 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     const float ox = s.x, oy = s.y;
     float pd = 0.f, d = 0.f;  // AG:24-25: a done agent returns (0, 0) and does not move
     if (!was_done) {
-        axis_update(ax, p.tau, p.amax, p.vmax, s.vx, s.x);  // AG:26-29
-        axis_update(ay, p.tau, p.amax, p.vmax, s.vy, s.y);
+        axis_update(ax, p.tau, p.rtau, p.recip_ok != 0, p.amax, p.vmax, s.vx, s.x);  // AG:26-29
+        axis_update(ay, p.tau, p.rtau, p.recip_ok != 0, p.amax, p.vmax, s.vy, s.y);
         pd = s.prev_d;                                       // AG:32
     }
     const float tdx = s.tx - s.x, tdy = s.ty - s.y;
@@ -550,6 +565,25 @@ double sq_threshold(double lim) {
     return s;
 }
 
+// div_tau() on the device replaces x/tau by a reciprocal + two fma; confirm on this tau that the
+// form returns the IEEE quotient (differences a - v of the magnitudes the kinematics produce, plus
+// the band |x| < amax*tau where the quotient is not clipped away).
+bool recip_division_exact(double tau) {
+    const double r = 1.0 / tau;
+    uint64_t s0 = 0x9E3779B97F4A7C15ull, s1 = 0xD1B54A32D192ED03ull;
+    for (int i = 0; i < 100000; i++) {
+        uint64_t a = s0, b = s1;
+        s0 = b; a ^= a << 23; s1 = a ^ b ^ (a >> 17) ^ (b >> 26);
+        const uint64_t u = s1 + b;
+        double x = ((double)(u >> 11) / 9007199254740992.0) * 2.0 - 1.0;  // (-1, 1)
+        x = std::ldexp(x, (i % 3 == 0) ? 5 : ((i % 3 == 1) ? -3 : -(int)(u % 60)));
+        const double q0 = x * r;
+        const double q = std::fma(std::fma(-q0, tau, x), r, q0);
+        if (q != x / tau) return false;
+    }
+    return true;
+}
+
 // float32 limits for threshold tests on squared distances (host sqrtf is correctly rounded):
 // smallest s with sqrtf(s) >= lim   ->   sqrtf(s) <  lim  <=>  s <  result
 float sq_limit_lt(float lim) {
@@ -643,6 +677,8 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     std::memset(&p, 0, sizeof p);
     const int N = cfg->num_agents;
     p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
+    p.rtau = 1.0 / cfg->tau;
+    p.recip_ok = recip_division_exact(cfg->tau) ? 1 : 0;
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
     p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
     p.speed_sq_lim = sq_threshold(0.2);
