@@ -18,7 +18,8 @@ F32, F64 = 0, 1
 SYMBOLS = (
     "uavx_version", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
     "uavx_num_agents", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
-    "uavx_set_state", "uavx_get_metrics", "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
+    "uavx_set_state", "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
+    "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
     "uavx_uw_reset", "uavx_uw_step", "uavx_uw_observe", "uavx_uw_get_state", "uavx_uw_set_state",
 )
 
@@ -40,6 +41,16 @@ class StateView(ctypes.Structure):
 
 
 UWStateView = StateView  # same field list (uavx_uw_state_view)
+
+ACTION_CARTESIAN, ACTION_POLAR = 0, 1
+RESET_NEVER, RESET_AGENT0_DONE, RESET_ALL_DONE = 0, 1, 2
+
+
+class StepArgs(ctypes.Structure):  # uavx_step_args
+    _fields_ = [("actions", ctypes.c_void_p), ("action_dtype", ctypes.c_int32), ("action_mode", ctypes.c_int32),
+                ("evaluate", ctypes.c_int32), ("reset_policy", ctypes.c_int32), ("step_cap", ctypes.c_uint32),
+                ("track_returns", ctypes.c_int32), ("seed", ctypes.c_uint64), ("obs", ctypes.c_void_p),
+                ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p)]
 
 _lib = None
 
@@ -80,6 +91,9 @@ def load():
     L.uavx_get_state.argtypes = [vp, ctypes.POINTER(StateView), vp]
     L.uavx_set_state.argtypes = [vp, ctypes.POINTER(StateView), vp]
     L.uavx_get_metrics.argtypes = [vp, vp, vp]
+    L.uavx_step_ex.argtypes = [vp, ctypes.POINTER(StepArgs), vp]
+    L.uavx_get_episode_stats.argtypes = [vp, vp, vp, vp]
+    L.uavx_clear_episode_stats.argtypes = [vp, vp]
     L.uavx_uw_create.argtypes = [ctypes.POINTER(UWConfig), i64, i64, i32, ctypes.POINTER(vp)]
     L.uavx_uw_destroy.argtypes = [vp]
     L.uavx_uw_last_error.argtypes = [vp]

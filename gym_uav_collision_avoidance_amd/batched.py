@@ -189,6 +189,53 @@ class BatchedMultiUAVWorld2D(_Base):
                                      rew.data_ptr(), done.data_ptr(), self._stream()), self._h)
         return obs, rew, done.view(torch.bool), {"distance": 0}
 
+    _POLICIES = {None: _lib.RESET_NEVER, "never": _lib.RESET_NEVER, "agent0_done": _lib.RESET_AGENT0_DONE,
+                 "all_done": _lib.RESET_ALL_DONE}
+
+    def step_ex(self, actions, evaluate=False, polar=False, auto_reset=None, step_cap=0, track_returns=True,
+                out=None):
+        """env.step plus what the reference's trainer loops do around it, in the same launch:
+          polar=True       actions are policy outputs a in [-1,1]^2, converted like test_sac_multi.py:77-80
+          auto_reset       "agent0_done" (test_sac_multi.py:112) / "all_done" (:116,161) / None; step_cap (:17,67)
+          track_returns    accumulate episode return / evaluation score per env (:106,157)
+        Auto-reset is next-step: an ended env keeps its terminal observation in this call's outputs and
+        is re-initialised by the NEXT call instead of being stepped (that call's reset_mask[e] is True,
+        reward 0, done False).  Returns (obs, rew, done, info) with info["reset_mask"] [E] bool."""
+        a, code = self._actions_arg(actions, (self.num_envs, self.num_agents, 2))
+        if out is None:
+            obs, rew, done = self._next_obs_buf(), self._rew, self._done
+        else:
+            obs, rew, done = out
+            done = done.view(torch.uint8) if done.dtype == torch.bool else done
+        if not hasattr(self, "_reset_mask"):
+            self._reset_mask = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+        args = _lib.StepArgs(a.data_ptr(), code, _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN,
+                             int(bool(evaluate)), self._POLICIES[auto_reset], int(step_cap), int(bool(track_returns)),
+                             self.seed, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), self._reset_mask.data_ptr())
+        _lib.check(self._L.uavx_step_ex(self._h, ctypes.byref(args), self._stream()), self._h)
+        return obs, rew, done.view(torch.bool), {"distance": 0, "reset_mask": self._reset_mask.view(torch.bool)}
+
+    def episode_stats(self):
+        """Statistics over the episodes ended so far (auto-reset or reset()): dict of [E] tensors
+        episodes, steps, reach, coll (int32) and return0, score (float32); see uavx_get_episode_stats."""
+        c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)
+        r = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.uavx_get_episode_stats(self._h, c.data_ptr(), r.data_ptr(), self._stream()), self._h)
+        return dict(episodes=c[:, 0], steps=c[:, 1], reach=c[:, 2], coll=c[:, 3], return0=r[:, 0], score=r[:, 1])
+
+    def clear_episode_stats(self):
+        _lib.check(self._L.uavx_clear_episode_stats(self._h, self._stream()), self._h)
+
+    def evaluation_summary(self):
+        """SR, CR and average score exactly as test_sac_multi.py:174-176 computes them, over all ended episodes."""
+        st = self.episode_stats()
+        episodes = int(st["episodes"].sum().item())
+        denom = max(1, self.num_agents * episodes)
+        return dict(episodes=episodes, success_rate=float(st["reach"].sum().item()) / denom,
+                    collision_rate=float(st["coll"].sum().item()) / denom,
+                    avg_score=float(st["score"].double().sum().item()) / denom,
+                    mean_steps=float(st["steps"].sum().item()) / max(1, episodes))
+
     def step_k(self, action_tape, evaluate=False, tape_out=False):
         """K steps in one launch from an action tape [K, E, N, 2] (open-loop rollouts, benchmarks).
         tape_out=False returns the last step's (obs, rew, done); True returns [K, ...] tapes."""

@@ -58,6 +58,19 @@ struct MultiParams {
     double2 *vel;
     Goal *goal;
     uint32_t *steps, *reach, *coll, *episode;
+    // episode bookkeeping (uavx_step_ex / uavx_reset)
+    uint8_t *pending;   // [E] env ended its episode: re-initialise it at the next step_ex call
+    float2 *ep_run;     // [E] running {agent-0 return, sum_i r_i*(1-done_i)} of the current episode
+    uint4 *fin_counts;  // [E] over ended episodes: {episodes, steps, target_reach_count, collision_count}
+    float2 *fin_returns;  // [E] over ended episodes: {agent-0 return sum, evaluation score sum}
+};
+
+// options of uavx_step_ex that the kernel needs (uavx_step_args minus the buffers)
+struct StepExtra {
+    int action_mode, reset_policy, track_returns;
+    uint32_t step_cap;
+    uint32_t seed_lo, seed_hi;
+    uint8_t *reset_mask;
 };
 
 struct LaneMap {
@@ -73,14 +86,14 @@ template <int NT>
 __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     LaneMap m;
     const int N = NT ? NT : p.N;
-    const int epw = NT ? (kWave / NT) : p.epw;
+    const int epw = NT ? (kWave / (NT ? NT : 1)) : p.epw;
     m.lane = threadIdx.x & (kWave - 1);
     m.wib = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + m.wib;
     int g;
     if (NT) {
-        g = m.lane / NT;
-        m.i = m.lane % NT;
+        g = m.lane / (NT ? NT : 1);
+        m.i = m.lane % (NT ? NT : 1);
     } else {
         g = (m.lane * p.magic) >> 16;  // floor(lane / N) for lane < 64
         m.i = m.lane - g * N;
@@ -280,11 +293,12 @@ __device__ __forceinline__ void store_obs_block(const MultiParams &p, const Lane
 template <int NT>
 __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &m, Lds &lds, AgentRegs &s, double ax,
                                            double ay, int evaluate, float o[10], float &rew, uint32_t &done_out,
-                                           uint32_t &reach_ev, uint32_t &coll_ev) {
+                                           uint32_t &reach_ev, uint32_t &coll_ev, bool frozen = false) {
+    // frozen: the env was re-initialised by this call (auto-reset); the agent only observes.
     const bool was_done = (s.flags & UAVX_FLAG_DONE) != 0;
     const float ox = s.x, oy = s.y;
     float pd = 0.f, d = 0.f;  // AG:24-25: a done agent returns (0, 0) and does not move
-    if (!was_done) {
+    if (!was_done && !frozen) {
         axis_update(ax, p.tau, p.rtau, p.recip_ok != 0, p.amax, p.vmax, s.vx, s.x);  // AG:26-29
         axis_update(ay, p.tau, p.rtau, p.recip_ok != 0, p.amax, p.vmax, s.vy, s.y);
         pd = s.prev_d;                                       // AG:32
@@ -315,7 +329,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     const bool collision = nb.step_sq_min <= p.sq_two_r;     // MUW:203  dist <= 2R
     if (collision) r = -2.0f;                                // MUW:204
     coll_ev = 0;
-    if (nb.step_sq_min <= p.sq_hard && !(s.flags & (UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED))) {  // MUW:207-208
+    if (nb.step_sq_min <= p.sq_hard && !(s.flags & (UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED)) && !frozen) {  // MUW:207-208
         coll_ev = 1;                                         // MUW:209
         s.flags |= UAVX_FLAG_COLLIDED;                       // MUW:210
     }
@@ -324,7 +338,10 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);
     float speed = __builtin_amdgcn_sqrtf((float)sq);         // obs feature only
     reach_ev = 0;
-    if (d < 0.5f && !collision && sq < p.speed_sq_lim) {     // MUW:218
+    if (frozen) {
+        done_out = 0;
+        r = 0.f;
+    } else if (d < 0.5f && !collision && sq < p.speed_sq_lim) {     // MUW:218
         done_out = 1;
         reach_ev = was_done ? 0u : 1u;                       // MUW:220-221
         s.flags |= UAVX_FLAG_DONE;                           // AG:39
@@ -339,7 +356,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     } else {
         done_out = 0;
     }
-    s.prev_d = d;                                            // MUW:229
+    if (!frozen) s.prev_d = d;                               // MUW:229
     rew = r;
     assemble_obs(p, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);  // MUW:233-235
 }
@@ -378,6 +395,179 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
         if (m.i == 0) atomicAdd(&p.steps[m.e], 1u);          // MUW:238 (no-return atomic: nothing waits on it)
+    }
+    store_obs_block<NT>(p, m, lds, o, obs_out);
+}
+
+// Start/target layout of one env with the reference's rejection rules (MUW:126-153); `st` abstracts where
+// the points live (global arrays for reset_kernel, an LDS row for the in-step auto-reset).
+template <class Store>
+__device__ __forceinline__ void sample_layout(const MultiParams &p, PhiloxDraws &rng, int N, Store st) {
+    for (int i = 0; i < N; i++) {  // MUW:126-137
+        float x, y;
+        bool replicated = true;
+        while (replicated) {
+            rng.point32(p.lox, p.loy, p.hix, p.hiy, x, y);
+            replicated = false;
+            for (int j = 0; j < i; j++) {
+                const float2 o = st.loc(j);
+                if (norm32(o.x - x, o.y - y) <= p.two_r_reset) { replicated = true; break; }  // MUW:135
+            }
+        }
+        st.set_loc(i, x, y);
+    }
+    for (int i = 0; i < N; i++) {  // MUW:140-153
+        const float2 me = st.loc(i);
+        float tx, ty;
+        bool replicated = true;
+        while (replicated) {
+            rng.point32(p.lox, p.loy, p.hix, p.hiy, tx, ty);
+            replicated = norm32(tx - me.x, ty - me.y) <= p.two_r_reset;  // MUW:146
+            for (int j = 0; j < i && !replicated; j++) {
+                const float2 o = st.tgt(j);
+                if (norm32(o.x - tx, o.y - ty) <= p.two_r_reset) replicated = true;  // MUW:151
+            }
+        }
+        st.set_tgt(i, tx, ty);
+    }
+}
+
+struct GlobalLayout {  // points go straight to the state arrays
+    float4 *dyn; Goal *goal;
+    __device__ float2 loc(int j) const { const float4 d = dyn[j]; return make_float2(d.x, d.y); }
+    __device__ float2 tgt(int j) const { return make_float2(goal[j].tx, goal[j].ty); }
+    __device__ void set_loc(int i, float x, float y) { dyn[i] = make_float4(x, y, 0.f, __uint_as_float(0u)); }
+    __device__ void set_tgt(int i, float x, float y) { goal[i].tx = x; goal[i].ty = y; }
+};
+struct LdsLayout {  // {x, y, tx, ty} per agent in the env's LDS row
+    float4 *row;
+    __device__ float2 loc(int j) const { return make_float2(row[j].x, row[j].y); }
+    __device__ float2 tgt(int j) const { return make_float2(row[j].z, row[j].w); }
+    __device__ void set_loc(int i, float x, float y) { row[i].x = x; row[i].y = y; }
+    __device__ void set_tgt(int i, float x, float y) { row[i].z = x; row[i].w = y; }
+};
+
+// An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation
+// loop reads (test_sac_multi.py:157,164-165) and clear the running values.  One lane per env.
+__device__ __forceinline__ void fold_episode(const MultiParams &p, uint32_t e, uint32_t steps) {
+    if (steps != 0) {
+        uint4 c = p.fin_counts[e];
+        c.x += 1; c.y += steps; c.z += p.reach[e]; c.w += p.coll[e];
+        p.fin_counts[e] = c;
+        const float2 run = p.ep_run[e];
+        float2 f = p.fin_returns[e];
+        f.x += run.x; f.y += run.y;
+        p.fin_returns[e] = f;
+    }
+    p.ep_run[e] = make_float2(0.f, 0.f);
+    p.reach[e] = 0; p.coll[e] = 0;  // MUW:167-168
+    p.episode[e] += 1;
+    p.pending[e] = 0;
+}
+
+// sin(pi*t), cos(pi*t) in float32: quarter-turn reduction + Taylor polynomials on |r| <= 1/4
+// (|error| < 1e-7).  Fixed fmaf sequence so the CPU oracle can restate it bit for bit.
+__device__ __forceinline__ void sincospi32(float t, float &sn, float &cs) {
+    const float k = rintf(2.0f * t);
+    const float r = fmaf(-0.5f, k, t);
+    const float z = r * r;
+    float ps = fmaf(z, 0.0821458866f, -0.599264529f);    //  pi^9/9!, -pi^7/7!
+    ps = fmaf(ps, z, 2.55016404f);                       //  pi^5/5!
+    ps = fmaf(ps, z, -5.16771278f);                      // -pi^3/3!
+    ps = fmaf(ps, z, 3.14159265f);
+    ps = ps * r;
+    float pc = fmaf(z, -0.0258068913f, 0.235330630f);    // -pi^10/10!, pi^8/8!
+    pc = fmaf(pc, z, -1.33526277f);                      // -pi^6/6!
+    pc = fmaf(pc, z, 4.05871213f);                       //  pi^4/4!
+    pc = fmaf(pc, z, -4.93480220f);                      // -pi^2/2!
+    pc = fmaf(pc, z, 1.0f);
+    const int q = (int)k & 3;
+    sn = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    cs = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+
+// test_sac_multi.py:77-80 in float32: a in [-1,1]^2 -> velocity command.
+__device__ __forceinline__ void polar_to_command(const MultiParams &p, float a0, float a1, double &ax, double &ay) {
+    const float v = fmaf(a0, 0.5f, 0.5f) * p.vmax_norm;
+    float sn, cs;
+    sincospi32(a1, sn, cs);
+    ax = (double)(v * cs);
+    ay = (double)(v * sn);
+}
+
+// uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
+// episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
+template <int NT, bool ACT64>
+__global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+                                                         int evaluate, float *__restrict__ obs_out,
+                                                         float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
+    __shared__ Lds lds;
+    const int N = NT ? NT : p.N;
+    const LaneMap m = lane_map<NT>(p);
+    AgentRegs s = {};
+    double ax = 0.0, ay = 0.0;
+    uint32_t steps_v = 0;
+    bool do_reset = false;
+    if (m.active) {
+        load_agent(p, m.a, s);
+        load_action<ACT64>(actions, m.a, ax, ay);
+        if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
+        do_reset = p.pending[m.e] != 0;
+        steps_v = p.steps[m.e];
+    }
+    if (__ballot(do_reset) != 0ull) {  // wave-uniform: at least one env of this wave starts a new episode
+        if (do_reset && m.i == 0) {    // the env's first lane draws the layout into the env's LDS row (MUW:126-153)
+            const uint64_t ge = (uint64_t)p.env_offset + m.e;
+            PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[m.e], x.seed_lo, x.seed_hi, 0u};
+            sample_layout(p, rng, N, LdsLayout{&lds.pos[m.wib][m.base]});
+            fold_episode(p, m.e, steps_v);
+        }
+        wave_lds_sync();
+        if (do_reset) {
+            const float4 q = lds.pos[m.wib][m.lane];
+            s.x = q.x; s.y = q.y; s.tx = q.z; s.ty = q.w;
+            s.init_d = s.prev_d = norm32(s.tx - s.x, s.ty - s.y);  // MUW:154-155
+            s.vx = 0.0; s.vy = 0.0; s.flags = 0;                   // MUW:120-123
+            p.goal[m.a] = Goal{s.tx, s.ty, s.init_d};
+            steps_v = 0;                                           // MUW:166
+        }
+        wave_lds_sync();
+    }
+    float o[10], rew;
+    uint32_t dn, re, ce;
+    step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset);
+    // episode end test for the NEXT call (test_sac_multi.py:67,112,116)
+    const unsigned long long done_bits = __ballot(dn != 0);
+    const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    const bool all_done = ((done_bits >> m.base) & group) == group;
+    if (x.track_returns) {
+        if (m.active) lds.theta[m.wib][m.lane] = do_reset ? 0.f : rew * (1.0f - (float)dn);  // test_sac_multi.py:157
+        wave_lds_sync();
+    }
+    if (m.active) {
+        store_agent(p, m.a, s);
+        rew_out[m.a] = rew;
+        done_out[m.a] = (uint8_t)dn;
+        if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
+        if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
+        if (m.i == 0) {
+            const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;  // MUW:238
+            bool ended = (x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
+                         (x.reset_policy == UAVX_RESET_ALL_DONE && all_done) ||
+                         (x.step_cap != 0 && steps_next >= x.step_cap);
+            ended = ended && !do_reset;
+            p.steps[m.e] = steps_next;
+            p.pending[m.e] = ended ? 1 : 0;
+            if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
+            if (x.track_returns) {
+                float2 run = p.ep_run[m.e];
+                float score = 0.f;
+                for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.base + j];
+                run.x += do_reset ? 0.f : rew;               // test_sac_multi.py:106 score += rewards[0]
+                run.y += score;
+                p.ep_run[m.e] = run;
+            }
+        }
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
@@ -456,37 +646,34 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
     PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[e], (uint32_t)seed, (uint32_t)(seed >> 32), 0u};
     float4 *dyn = p.dyn + e * N;
     Goal *goal = p.goal + e * N;
-    for (int i = 0; i < N; i++) {  // MUW:126-137
-        float x, y;
-        bool replicated = true;
-        while (replicated) {
-            rng.point32(p.lox, p.loy, p.hix, p.hiy, x, y);
-            replicated = false;
-            for (int j = 0; j < i; j++) {
-                const float4 o = dyn[j];
-                if (norm32(o.x - x, o.y - y) <= p.two_r_reset) { replicated = true; break; }  // MUW:135
-            }
-        }
-        dyn[i] = make_float4(x, y, 0.f, __uint_as_float(0u));  // MUW:122-123 clears done/collided
-        p.vel[e * N + i] = make_double2(0.0, 0.0);               // MUW:120
-    }
-    for (int i = 0; i < N; i++) {  // MUW:140-155
+    sample_layout(p, rng, N, GlobalLayout{dyn, goal});
+    for (int i = 0; i < N; i++) {
         const float4 me = dyn[i];
-        float tx, ty;
-        bool replicated = true;
-        while (replicated) {
-            rng.point32(p.lox, p.loy, p.hix, p.hiy, tx, ty);
-            replicated = norm32(tx - me.x, ty - me.y) <= p.two_r_reset;  // MUW:146
-            for (int j = 0; j < i && !replicated; j++) {
-                if (norm32(goal[j].tx - tx, goal[j].ty - ty) <= p.two_r_reset) replicated = true;  // MUW:151
-            }
-        }
-        const float d0 = norm32(tx - me.x, ty - me.y);  // MUW:154
-        goal[i] = Goal{tx, ty, d0};
-        dyn[i] = make_float4(me.x, me.y, d0, __uint_as_float(0u));  // MUW:155 prev_distance = init_distance
+        const float d0 = norm32(goal[i].tx - me.x, goal[i].ty - me.y);  // MUW:154
+        goal[i].init_d = d0;
+        dyn[i] = make_float4(me.x, me.y, d0, __uint_as_float(0u));       // MUW:155, MUW:122-123
+        p.vel[e * N + i] = make_double2(0.0, 0.0);                        // MUW:120
     }
-    p.steps[e] = 0; p.reach[e] = 0; p.coll[e] = 0;  // MUW:166-168
-    p.episode[e] += 1;
+    fold_episode(p, (uint32_t)e, p.steps[e]);
+    p.steps[e] = 0;  // MUW:166
+}
+
+__global__ __launch_bounds__(kBlock) void episode_stats_kernel(MultiParams p, uint32_t *counts, float *returns, int clear) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.E) return;
+    if (clear) {
+        p.fin_counts[e] = make_uint4(0, 0, 0, 0);
+        p.fin_returns[e] = make_float2(0.f, 0.f);
+        return;
+    }
+    if (counts) {
+        const uint4 c = p.fin_counts[e];
+        counts[4 * e] = c.x; counts[4 * e + 1] = c.y; counts[4 * e + 2] = c.z; counts[4 * e + 3] = c.w;
+    }
+    if (returns) {
+        const float2 f = p.fin_returns[e];
+        returns[2 * e] = f.x; returns[2 * e + 1] = f.y;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_state_view v) {
@@ -619,6 +806,15 @@ void launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actio
     }
 }
 
+template <int NT>
+void launch_step_ex_nt(uavx_handle *h, dim3 grid, hipStream_t st, const StepExtra &x, const uavx_step_args *a) {
+    const dim3 blk(kBlock);
+    if (a->action_dtype == UAVX_F64)
+        hipLaunchKernelGGL((step_ex_kernel<NT, true>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+    else
+        hipLaunchKernelGGL((step_ex_kernel<NT, false>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+}
+
 dim3 wave_grid(const uavx_handle *h) {
     const int64_t waves = (h->p.E + h->p.epw - 1) / h->p.epw;
     return dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
@@ -708,6 +904,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_reach = off; off = align_up(off + E * 4, 256);
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
     const size_t o_epi = off;   off = align_up(off + E * 4, 256);
+    const size_t o_pend = off;  off = align_up(off + E, 256);
+    const size_t o_run = off;   off = align_up(off + E * sizeof(float2), 256);
+    const size_t o_finc = off;  off = align_up(off + E * sizeof(uint4), 256);
+    const size_t o_finr = off;  off = align_up(off + E * sizeof(float2), 256);
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     e = hipMemset(h->slab, 0, off);
@@ -720,6 +920,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.reach = reinterpret_cast<uint32_t *>(b + o_reach);
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
     p.episode = reinterpret_cast<uint32_t *>(b + o_epi);
+    p.pending = reinterpret_cast<uint8_t *>(b + o_pend);
+    p.ep_run = reinterpret_cast<float2 *>(b + o_run);
+    p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
+    p.fin_returns = reinterpret_cast<float2 *>(b + o_finr);
     *out = h;
     return UAVX_OK;
 }
@@ -799,6 +1003,54 @@ int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, in
 int uavx_step(uavx_handle *h, const void *actions, int action_dtype, int evaluate, float *obs, float *rew,
               uint8_t *done, void *stream) {
     return uavx_step_k(h, 1, actions, action_dtype, evaluate, 0, obs, rew, done, stream);
+}
+
+int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
+    if (!h || !a) return UAVX_ERR_INVALID_ARG;
+    if (!a->actions || !a->obs || !a->rew || !a->done) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: NULL buffer");
+    if (a->action_dtype != UAVX_F32 && a->action_dtype != UAVX_F64)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: action_dtype must be UAVX_F32 or UAVX_F64");
+    if (a->action_mode != UAVX_ACTION_CARTESIAN && a->action_mode != UAVX_ACTION_POLAR)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown action_mode");
+    if (a->reset_policy < UAVX_RESET_NEVER || a->reset_policy > UAVX_RESET_ALL_DONE)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown reset_policy");
+    if ((reinterpret_cast<uintptr_t>(a->obs) & 15u) || (reinterpret_cast<uintptr_t>(a->actions) & 15u) ||
+        (reinterpret_cast<uintptr_t>(a->rew) & 3u))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: obs/actions must be 16-byte aligned, rew 4-byte aligned");
+    UAVX_ENTER(h);
+    StepExtra x;
+    x.action_mode = a->action_mode; x.reset_policy = a->reset_policy; x.track_returns = a->track_returns;
+    x.step_cap = a->step_cap; x.seed_lo = (uint32_t)a->seed; x.seed_hi = (uint32_t)(a->seed >> 32);
+    x.reset_mask = a->reset_mask;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid = wave_grid(h);
+    switch (h->p.N) {
+        case 1: launch_step_ex_nt<1>(h, grid, st, x, a); break;
+        case 2: launch_step_ex_nt<2>(h, grid, st, x, a); break;
+        case 4: launch_step_ex_nt<4>(h, grid, st, x, a); break;
+        case 8: launch_step_ex_nt<8>(h, grid, st, x, a); break;
+        default: launch_step_ex_nt<0>(h, grid, st, x, a); break;
+    }
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_get_episode_stats(uavx_handle *h, uint32_t *counts, float *returns, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    hipLaunchKernelGGL(episode_stats_kernel, dim3((unsigned)((h->p.E + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, counts, returns, 0);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_clear_episode_stats(uavx_handle *h, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    hipLaunchKernelGGL(episode_stats_kernel, dim3((unsigned)((h->p.E + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, (uint32_t *)nullptr, (float *)nullptr, 1);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
 }
 
 int uavx_get_state(uavx_handle *h, const uavx_state_view *dst, void *stream) {

@@ -1,0 +1,80 @@
+"""On-device replay memory fed zero-copy by the step kernel (BASELINE config 5).
+
+The reference pushes (state, action, reward, next_state, float(not done)) per agent into a host
+python list (pytorch_sac_temp/replay_memory.py:15-24, test_sac_multi.py:101-103) and samples
+uniformly (:21-24).  Here the env's own output buffers ARE the memory: a time-major ring in HBM whose
+slot k holds what step k produced, and the step launch writes observation / reward / done of step k
+straight into slots k+1 / k / k — nothing is copied and s'(k) is s(k+1) by construction, so every
+observation is stored once.  Rows where the env was re-initialised instead of stepped (auto-reset,
+`reset_mask`) are not transitions and are never returned by sample().
+"""
+import torch
+
+from . import _lib
+
+
+class DeviceReplay:
+    def __init__(self, env, horizon):
+        """env: BatchedMultiUAVWorld2D; horizon: number of most recent steps kept (capacity in
+        transitions = horizon * num_envs * num_agents)."""
+        self.env, self.T = env, int(horizon)
+        L, E, N, dev = self.T + 1, env.num_envs, env.num_agents, env.device
+        self.L = L
+        self.obs = torch.zeros((L, E, N, _lib.OBS_DIM), dtype=torch.float32, device=dev)
+        self.act = torch.zeros((L, E, N, 2), dtype=torch.float32, device=dev)
+        self.rew = torch.zeros((L, E, N), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((L, E, N), dtype=torch.uint8, device=dev)
+        self.skip = torch.zeros((L, E), dtype=torch.uint8, device=dev)
+        self.count = 0  # steps written so far
+
+    def __len__(self):
+        return min(self.count, self.T) * self.env.num_envs * self.env.num_agents
+
+    def begin(self, obs0):
+        """Stores the observation the first step starts from (what env.reset() returned)."""
+        self.obs[self.count % self.L].copy_(obs0)
+
+    @property
+    def state(self):
+        """Current observation s(k) — feed this to the policy."""
+        return self.obs[self.count % self.L]
+
+    def action_slot(self):
+        """[E, N, 2] float32 view the policy can write its output into (no copy at step time)."""
+        return self.act[self.count % self.L]
+
+    def step(self, actions=None, **step_ex_kwargs):
+        """Steps the env with `actions` (or whatever was written into action_slot()); outputs land in the ring."""
+        k = self.count % self.L
+        if actions is not None:
+            self.act[k].copy_(actions)
+        nxt = (self.count + 1) % self.L
+        obs, rew, done, info = self.env.step_ex(self.act[k], out=(self.obs[nxt], self.rew[k], self.done[k]),
+                                                **step_ex_kwargs)
+        self.skip[k].copy_(info["reset_mask"])
+        self.count += 1
+        return obs, rew, done, info
+
+    def sample(self, batch_size, generator=None):
+        """Uniform batch of transitions like ReplayMemory.sample (replay_memory.py:21-24):
+        (state [B,10], action [B,2], reward [B], next_state [B,10], mask [B] = 1 - done).  Fixed size, no host sync."""
+        assert self.count > 0
+        E, N, dev = self.env.num_envs, self.env.num_agents, self.env.device
+        lo = max(0, self.count - self.T)
+        span = self.count - lo
+
+        def draw():
+            r = torch.rand((3, batch_size), generator=generator, device=dev)
+            k = lo + (r[0] * span).long().clamp_(max=span - 1)
+            return k, (r[1] * E).long().clamp_(max=E - 1), (r[2] * N).long().clamp_(max=N - 1)
+
+        k, e, i = draw()
+        k2, e2, i2 = draw()  # one redraw for rows that hit a reset step (rare: one per episode per env)
+        bad = self.skip[k % self.L, e] != 0
+        k, e, i = torch.where(bad, k2, k), torch.where(bad, e2, e), torch.where(bad, i2, i)
+        bad = self.skip[k % self.L, e] != 0
+        # a reset step is never followed or preceded by another one: fall back to the neighbouring step
+        k = torch.where(bad, torch.where(k > lo, k - 1, k + 1), k)
+        s, s1 = k % self.L, (k + 1) % self.L
+        return (self.obs[s, e, i], self.act[s, e, i], self.rew[s, e, i], self.obs[s1, e, i],
+                1.0 - self.done[s, e, i].float())

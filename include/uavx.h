@@ -123,6 +123,52 @@ int uavx_step(uavx_handle *h, const void *actions, int action_dtype, int evaluat
 int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, int evaluate,
                 int tape_out, float *obs, float *rew, uint8_t *done, void *stream);
 
+/* ---- the trainer loop's work around env.step, fused into the step launch ----
+ * The reference's callers (a) convert a policy output a in [-1,1]^2 to a velocity command
+ * (test_sac_multi.py:77-80), (b) add up rewards and read the counters at episode end
+ * (test_sac_multi.py:106,157,164-165) and (c) reset the env on dones[0] (training, :112), all(dones)
+ * (evaluation, :116,161) or a step cap (:17,67).  uavx_step_ex does all three on the device. */
+typedef enum {
+    UAVX_ACTION_CARTESIAN = 0, /* actions are velocity commands (what env.step takes) */
+    UAVX_ACTION_POLAR = 1      /* actions are a in [-1,1]^2: v = (a0/2+0.5)*||action_space.high||, theta = a1*pi,
+                                  command = (v cos theta, v sin theta), float32 arithmetic */
+} uavx_action_mode;
+typedef enum {
+    UAVX_RESET_NEVER = 0,       /* like the reference: the caller resets */
+    UAVX_RESET_AGENT0_DONE = 1, /* test_sac_multi.py:112 */
+    UAVX_RESET_ALL_DONE = 2     /* test_sac_multi.py:116,161 */
+} uavx_reset_policy;
+
+typedef struct {
+    const void *actions;   /* [E*N*2] */
+    int32_t action_dtype;  /* uavx_dtype */
+    int32_t action_mode;   /* uavx_action_mode */
+    int32_t evaluate;      /* MUW:177 */
+    int32_t reset_policy;  /* uavx_reset_policy */
+    uint32_t step_cap;     /* 0 = none; an env whose `steps` reaches the cap ends its episode too */
+    int32_t track_returns; /* accumulate per-env episode return / evaluation score */
+    uint64_t seed;         /* Philox key for the auto-resets */
+    float *obs;            /* [E*N*10] */
+    float *rew;            /* [E*N] */
+    uint8_t *done;         /* [E*N] */
+    uint8_t *reset_mask;   /* [E] or NULL: 1 where this call re-initialised the env instead of stepping it */
+} uavx_step_args;
+
+/* Auto-reset is "next-step": an env whose episode ended at call t keeps its terminal observation in
+ * that call's outputs (so s' of the last transition is the true successor) and is re-initialised by
+ * call t+1 INSTEAD of being stepped: that call returns the fresh observation with reward 0, done 0
+ * and reset_mask 1 for the env, and its action is ignored.  Ended episodes are folded into the
+ * per-env episode statistics (also by uavx_reset). */
+int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
+
+/* Per-env statistics over the episodes ended so far (by auto-reset or uavx_reset):
+ * counts  [E*4] uint32 = episodes, sum of steps, sum of target_reach_count, sum of collision_count
+ * returns [E*2] float32 = sum of agent-0 returns (test_sac_multi.py:106 `score`),
+ *                         sum of sum_i r_i*(1-done_i) (test_sac_multi.py:157 `total_score`)
+ * SR/CR of test_sac_multi.py:174-175 = sum(reach or coll) / (N * sum(episodes)).  Either may be NULL. */
+int uavx_get_episode_stats(uavx_handle *h, uint32_t *counts, float *returns, void *stream);
+int uavx_clear_episode_stats(uavx_handle *h, void *stream);
+
 /* Replaces MultiUAVWorld2D._get_obs for every agent (MUW:60-109): obs [E*N*10] float32. */
 int uavx_observe(uavx_handle *h, float *obs, void *stream);
 

@@ -45,6 +45,16 @@ class _State(ctypes.Structure):
                 ("counters", ctypes.c_void_p), ("f64pos", ctypes.c_void_p)]
 
 
+class _StepOpts(ctypes.Structure):
+    _fields_ = [("action_mode", ctypes.c_int32), ("reset_policy", ctypes.c_int32), ("track_returns", ctypes.c_int32),
+                ("step_cap", ctypes.c_uint32), ("seed", ctypes.c_uint64), ("env_offset", ctypes.c_int64)]
+
+
+class _EpisodeState(ctypes.Structure):
+    _fields_ = [("pending", ctypes.c_void_p), ("ep_run", ctypes.c_void_p), ("fin_counts", ctypes.c_void_p),
+                ("fin_returns", ctypes.c_void_p)]
+
+
 class _UWConfig(ctypes.Structure):
     _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("max_speed", ctypes.c_double),
                 ("max_acceleration", ctypes.c_double), ("tau", ctypes.c_double)]
@@ -78,6 +88,12 @@ def lib():
         L.uavo_reset_philox.argtypes = [vp, vp, vp, u64, i64, i32]
         L.uavo_observe.argtypes = [vp, vp, vp, i32]
         L.uavo_step.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32]
+        L.uavo_polar_to_command.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
+        L.uavo_polar_to_command.restype = None
+        L.uavo_step_ex.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32]
+        L.uavo_step_ex.restype = None
+        L.uavo_fold_episode.argtypes = [vp, vp, i64]
+        L.uavo_fold_episode.restype = None
         L.uavo_uw_reset_mt.argtypes = [vp, vp, i64, vp]
         L.uavo_uw_reset_philox.argtypes = [vp, vp, vp, u64, i64, i32]
         L.uavo_uw_observe.argtypes = [vp, vp, vp, i32]
@@ -91,6 +107,12 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def polar_to_command(a0, a1, vmax_norm):
+    out = np.zeros(2, np.float64)
+    lib().uavo_polar_to_command(float(a0), float(a1), float(vmax_norm), _p(out))
+    return out
 
 
 def philox4x32(ctr, key):
@@ -133,6 +155,12 @@ class OracleMulti:
         self.f64pos = np.zeros((E,), np.uint8)
         self._st = _State(E, N, 0, _p(self.loc), _p(self.vel), _p(self.tgt), _p(self.init_d),
                           _p(self.prev_d), _p(self.flags), _p(self.counters), _p(self.f64pos))
+        # episode bookkeeping of uavx_step_ex / uavx_reset
+        self.pending = np.zeros((E,), np.uint8)
+        self.ep_run = np.zeros((E, 2), np.float32)
+        self.fin_counts = np.zeros((E, 4), np.uint32)
+        self.fin_returns = np.zeros((E, 2), np.float32)
+        self._ep = _EpisodeState(_p(self.pending), _p(self.ep_run), _p(self.fin_counts), _p(self.fin_returns))
 
     # -- state exchange with the device path (float32 positions) -----------------------------------
     def get_state(self):
@@ -152,8 +180,24 @@ class OracleMulti:
 
     def reset_philox(self, seed, mask=None, env_offset=0):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        for e in range(self.E):  # an explicit reset ends the running episode (uavx_reset does the same)
+            if m is None or m[e]:
+                lib().uavo_fold_episode(ctypes.byref(self._st), ctypes.byref(self._ep), e)
         lib().uavo_reset_philox(ctypes.byref(self.cfg), ctypes.byref(self._st),
                                 None if m is None else _p(m), int(seed), int(env_offset), self.nthreads)
+
+    def step_ex(self, actions, evaluate=False, action_mode=0, reset_policy=0, step_cap=0, track_returns=False,
+                seed=0, env_offset=0):
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(self.E, self.N, 2))
+        obs = np.empty((self.E, self.N, OBS_DIM), np.float64)
+        rew = np.empty((self.E, self.N), np.float64)
+        done = np.empty((self.E, self.N), np.uint8)
+        rmask = np.zeros((self.E,), np.uint8)
+        opt = _StepOpts(int(action_mode), int(reset_policy), int(bool(track_returns)), int(step_cap), int(seed),
+                        int(env_offset))
+        lib().uavo_step_ex(ctypes.byref(self.cfg), ctypes.byref(self._st), ctypes.byref(self._ep), ctypes.byref(opt),
+                           _p(a), int(bool(evaluate)), _p(obs), _p(rew), _p(done), _p(rmask), self.nthreads)
+        return obs, rew, done, rmask
 
     def observe(self):
         obs = np.empty((self.E, self.N, OBS_DIM), np.float64)

@@ -398,6 +398,95 @@ void uavo_step(const uavo_config *cfg, uavo_state *st, const double *actions, in
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * uavx_step_ex restatement (new semantics; see header)
+ * ---------------------------------------------------------------------------------------------- */
+static void sincospi32(float t, float *sn, float *cs) {
+    const float k = rintf(2.0f * t);
+    const float r = fmaf(-0.5f, k, t);
+    const float z = r * r;
+    float ps = fmaf(z, 0.0821458866f, -0.599264529f);
+    ps = fmaf(ps, z, 2.55016404f);
+    ps = fmaf(ps, z, -5.16771278f);
+    ps = fmaf(ps, z, 3.14159265f);
+    ps = ps * r;
+    float pc = fmaf(z, -0.0258068913f, 0.235330630f);
+    pc = fmaf(pc, z, -1.33526277f);
+    pc = fmaf(pc, z, 4.05871213f);
+    pc = fmaf(pc, z, -4.93480220f);
+    pc = fmaf(pc, z, 1.0f);
+    const int q = (int)k & 3;
+    *sn = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    *cs = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+
+void uavo_polar_to_command(float a0, float a1, float vmax_norm, double out[2]) {
+    const float v = fmaf(a0, 0.5f, 0.5f) * vmax_norm; /* test_sac_multi.py:77 */
+    float sn, cs;
+    sincospi32(a1, &sn, &cs);                         /* :78 theta = a1*pi */
+    out[0] = (double)(v * cs);                        /* :80 */
+    out[1] = (double)(v * sn);
+}
+
+void uavo_fold_episode(uavo_state *st, uavo_episode_state *ep, int64_t e) {
+    uint32_t *c = st->counters + e * 4;
+    if (c[0] != 0) {
+        ep->fin_counts[4 * e + 0] += 1;
+        ep->fin_counts[4 * e + 1] += c[0];
+        ep->fin_counts[4 * e + 2] += c[1];
+        ep->fin_counts[4 * e + 3] += c[2];
+        ep->fin_returns[2 * e + 0] += ep->ep_run[2 * e + 0];
+        ep->fin_returns[2 * e + 1] += ep->ep_run[2 * e + 1];
+    }
+    ep->ep_run[2 * e] = 0.f; ep->ep_run[2 * e + 1] = 0.f;
+    ep->pending[e] = 0;
+}
+
+void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep, const uavo_step_opts *opt,
+                  const double *actions, int evaluate, double *obs, double *reward, uint8_t *done,
+                  uint8_t *reset_mask, int nthreads) {
+    const int n = st->num_agents;
+    const float vmax_norm = (float)nrm64(cfg->max_speed, cfg->max_speed);
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) {
+        uint32_t *c = st->counters + e * 4;
+        if (ep->pending[e]) { /* the env starts a new episode instead of stepping */
+            draw_src s;
+            memset(&s, 0, sizeof s);
+            uint64_t ge = (uint64_t)(opt->env_offset + e);
+            s.key[0] = (uint32_t)opt->seed; s.key[1] = (uint32_t)(opt->seed >> 32);
+            s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
+            s.episode = c[3];
+            uavo_fold_episode(st, ep, e);
+            reset_env(cfg, st, e, &s, 0);
+            c[3] += 1;
+            observe_env(cfg, st, e, obs);
+            for (int i = 0; i < n; i++) { reward[e * n + i] = 0.0; done[e * n + i] = 0; }
+            if (reset_mask) reset_mask[e] = 1;
+            continue;
+        }
+        double act[2 * MAXN];
+        for (int i = 0; i < n; i++) {
+            const double *a = actions + (e * n + i) * 2;
+            if (opt->action_mode == 1) uavo_polar_to_command((float)a[0], (float)a[1], vmax_norm, act + 2 * i);
+            else { act[2 * i] = a[0]; act[2 * i + 1] = a[1]; }
+        }
+        step_env(cfg, st, e, act - (e * n) * 2, evaluate, obs, reward, done);
+        int all_done = 1;
+        for (int i = 0; i < n; i++) all_done &= done[e * n + i] != 0;
+        int ended = (opt->reset_policy == 1 && done[e * n]) || (opt->reset_policy == 2 && all_done) ||
+                    (opt->step_cap != 0 && c[0] >= opt->step_cap);
+        ep->pending[e] = (uint8_t)(ended ? 1 : 0);
+        if (reset_mask) reset_mask[e] = 0;
+        if (opt->track_returns) {
+            float score = 0.f;
+            for (int i = 0; i < n; i++) score += (float)reward[e * n + i] * (1.0f - (float)done[e * n + i]);
+            ep->ep_run[2 * e] += (float)reward[e * n];
+            ep->ep_run[2 * e + 1] += score;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * UAVWorld2D
  * ---------------------------------------------------------------------------------------------- */
 static void uw_observe_env(const uavo_uw_config *cfg, const uavo_uw_state *st, int64_t e, double *o) {

@@ -76,6 +76,34 @@ void uavo_observe(const uavo_config *cfg, const uavo_state *st, double *obs, int
 void uavo_step(const uavo_config *cfg, uavo_state *st, const double *actions, int evaluate,
                double *obs, double *reward, uint8_t *done, int nthreads);
 
+/* ---- trainer-loop fusions of uavx_step_ex (NEW semantics of the build, not reference behaviour: the
+ * env step inside is the pinned uavo_step; conversion / auto-reset / statistics restate what the
+ * reference's trainer scripts do around env.step, test_sac_multi.py:67-119,132-183) ---- */
+typedef struct {
+    int32_t action_mode;   /* 0 cartesian, 1 polar (test_sac_multi.py:77-80 in float32) */
+    int32_t reset_policy;  /* 0 never, 1 agent-0 done (:112), 2 all done (:116,161) */
+    int32_t track_returns;
+    uint32_t step_cap;     /* :17,67 */
+    uint64_t seed;
+    int64_t env_offset;
+} uavo_step_opts;
+
+typedef struct {
+    uint8_t *pending;      /* [E] */
+    float *ep_run;         /* [E*2] running {agent-0 return, sum_i r_i (1-done_i)} */
+    uint32_t *fin_counts;  /* [E*4] episodes, steps, reach, coll over ended episodes */
+    float *fin_returns;    /* [E*2] */
+} uavo_episode_state;
+
+/* float32 restatement of the device's polar -> velocity-command conversion (same fmaf sequence). */
+void uavo_polar_to_command(float a0, float a1, float vmax_norm, double out[2]);
+/* next-step auto-reset + statistics; reset_mask may be NULL. */
+void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep, const uavo_step_opts *opt,
+                  const double *actions, int evaluate, double *obs, double *reward, uint8_t *done,
+                  uint8_t *reset_mask, int nthreads);
+/* the statistics side of an explicit reset (uavx_reset folds the running episode the same way) */
+void uavo_fold_episode(uavo_state *st, uavo_episode_state *ep, int64_t env);
+
 /* ---- UAVWorld2D (UW) ---- */
 typedef struct {
     double x_size, y_size, max_speed, max_acceleration, tau;

@@ -1,0 +1,156 @@
+"""GPU tests of the trainer-loop fusions (uavx_step_ex: polar actions, next-step auto-reset, episode
+statistics) and the zero-copy device replay.  These are NEW semantics of the build:
+the env step inside is the reference-pinned one; the bookkeeping is checked against the oracle's
+restatement (oracle/uavx_oracle.c: uavo_step_ex) and against the reference trainers' own formulas."""
+import math
+
+import numpy as np
+import pytest
+
+from golden_util import obs_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    assert torch.cuda.is_available()
+    import gym_uav_collision_avoidance_amd as pkg
+    return pkg
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_polar_conversion_matches_the_trainers_formula(amd, oracle_mod):
+    """Device float32 conversion == oracle restatement bit for bit, and == test_sac_multi.py:77-80 to 1e-6."""
+    import torch
+    E, n = 4096, 4
+    env = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=1)
+    orc = oracle_mod.OracleMulti(num_envs=E, num_agents=n, nthreads=8)
+    env.reset()
+    orc.reset_philox(1)
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, size=(E, n, 2)).astype(np.float32)
+    a[0, 0] = [1.0, 1.0]; a[0, 1] = [-1.0, -1.0]; a[0, 2] = [0.0, 0.5]; a[0, 3] = [0.3, -0.5]
+    env.step_ex(torch.from_numpy(a).to(env.device), polar=True)
+    orc.step_ex(a, action_mode=1)
+    st = env.get_state()
+    np.testing.assert_array_equal(_np(st["vel"]), orc.vel)
+    np.testing.assert_array_equal(_np(st["loc"]), orc.loc.astype(np.float32))
+    vmax = np.linalg.norm(env.action_space.high)
+    for (a0, a1) in a.reshape(-1, 2)[:2000]:
+        v = (np.float64(a0) / 2 + 0.5) * np.float64(vmax)
+        th = np.float64(a1) * math.pi
+        want = np.array([v * math.cos(th), v * math.sin(th)])
+        got = oracle_mod.polar_to_command(a0, a1, np.float32(vmax))
+        assert np.abs(got - want).max() < 4e-6  # float32 arithmetic on |command| <= 14.2
+    env.close()
+
+
+@pytest.mark.parametrize("policy,code,cap,n", [("agent0_done", 1, 0, 4), ("all_done", 2, 90, 4), (None, 0, 40, 8),
+                                                 ("agent0_done", 1, 55, 5), ("all_done", 2, 70, 1)])
+def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, policy, code, cap, n):
+    import torch
+    E = 1536
+    kw = dict(x_size=26.0, y_size=26.0, num_agents=n, d_sense=9.0)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=77, env_offset=5, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.reset()
+    orc.reset_philox(77, env_offset=5)
+    rng = np.random.default_rng(3)
+    resets = 0
+    for t in range(260):
+        d = orc.tgt - orc.loc
+        dist = np.linalg.norm(d, axis=-1, keepdims=True)
+        act = d / np.maximum(dist, 1e-9) * np.where(dist > 0.3, np.minimum(8.0, np.sqrt(4.0 * dist)), 0.0)
+        act = act + rng.normal(0, 0.3, size=act.shape) * (dist > 2.0)
+        ev = policy == "all_done"
+        obs_g, rew_g, done_g, info = env.step_ex(act, evaluate=ev, auto_reset=policy, step_cap=cap, track_returns=True)
+        obs_o, rew_o, done_o, rmask_o = orc.step_ex(act, evaluate=ev, reset_policy=code, step_cap=cap, track_returns=True,
+                                                    seed=77, env_offset=5)
+        ctx = f"{policy}/{cap} step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rmask_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        resets += int(rmask_o.sum())
+        st = env.get_state()
+        ref = orc.get_state()
+        for key in ("loc", "vel", "tgt", "init_d", "prev_d", "flags"):
+            np.testing.assert_array_equal(_np(st[key]), ref[key], err_msg=f"{ctx} {key}")
+        np.testing.assert_array_equal(_np(st["counters"]), ref["counters"].astype(np.int32), err_msg=ctx)
+        assert obs_err(_np(obs_g), obs_o) <= TOL and float(np.abs(_np(rew_g) - rew_o).max()) <= TOL, ctx
+        assert (_np(rew_g)[rmask_o == 1] == 0).all() and (_np(done_g)[rmask_o == 1] == 0).all()
+    assert resets > E // 4, "scenario must actually auto-reset"
+    stats = {k: _np(v) for k, v in env.episode_stats().items()}
+    np.testing.assert_array_equal(stats["episodes"], orc.fin_counts[:, 0])
+    np.testing.assert_array_equal(stats["steps"], orc.fin_counts[:, 1])
+    np.testing.assert_array_equal(stats["reach"], orc.fin_counts[:, 2])
+    np.testing.assert_array_equal(stats["coll"], orc.fin_counts[:, 3])
+    np.testing.assert_allclose(stats["return0"], orc.fin_returns[:, 0], atol=2e-3, rtol=1e-5)
+    np.testing.assert_allclose(stats["score"], orc.fin_returns[:, 1], atol=2e-3, rtol=1e-5)
+    summ = env.evaluation_summary()
+    eps = int(orc.fin_counts[:, 0].sum())
+    assert summ["episodes"] == eps
+    assert summ["success_rate"] == pytest.approx(orc.fin_counts[:, 2].sum() / (n * eps))   # test_sac_multi.py:174
+    assert summ["collision_rate"] == pytest.approx(orc.fin_counts[:, 3].sum() / (n * eps))  # test_sac_multi.py:175
+    # an explicit reset also ends the running episodes
+    env.reset()
+    orc.reset_philox(77, env_offset=5)
+    np.testing.assert_array_equal(_np(env.episode_stats()["episodes"]), orc.fin_counts[:, 0])
+    env.clear_episode_stats()
+    assert int(env.episode_stats()["episodes"].sum()) == 0
+    env.close()
+
+
+def test_step_ex_defaults_equal_plain_step(amd):
+    import torch
+    E, n = 3000, 4
+    a = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=9)
+    b = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=9)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for t in range(30):
+        act = (torch.rand((E, n, 2), generator=g) * 20 - 10).to(a.device)
+        o1, r1, d1, _ = a.step(act)
+        o2, r2, d2, info = b.step_ex(act, track_returns=False)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and not info["reset_mask"].any()
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
+def test_device_replay_is_zero_copy_and_samples_true_transitions(amd):
+    import torch
+    from gym_uav_collision_avoidance_amd.replay import DeviceReplay
+    E, n, T = 512, 4, 16
+    env = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=4, x_size=26.0, y_size=26.0)
+    mem = DeviceReplay(env, horizon=T)
+    mem.begin(env.reset())
+    g = torch.Generator(device=env.device).manual_seed(0)
+    tape = []
+    for t in range(40):  # wraps the ring more than twice
+        s = mem.state.clone()
+        slot = mem.action_slot()
+        slot.copy_(torch.rand((E, n, 2), generator=g, device=env.device) * 2 - 1)  # "policy output" written in place
+        obs, rew, done, info = mem.step(polar=True, auto_reset="agent0_done", step_cap=12)
+        assert obs.data_ptr() == mem.obs[(t + 1) % (T + 1)].data_ptr()  # the kernel wrote straight into the ring
+        tape.append((s, slot.clone(), rew.clone(), obs.clone(), done.clone(), info["reset_mask"].clone()))
+    assert len(mem) == T * E * n
+    S, A, R, S1, M = mem.sample(20000, generator=g)
+    # every sampled row must be one of the true (non-reset) transitions of the last T steps
+    keys = {}
+    for (s, a, r, s1, d, rm) in tape[-T:]:
+        ok = ~rm
+        rows = torch.cat([s[ok].reshape(-1, 10), a[ok].reshape(-1, 2), r[ok].reshape(-1, 1), s1[ok].reshape(-1, 10),
+                          1 - d[ok].reshape(-1, 1).float()], dim=1)
+        for row in rows.cpu().numpy().round(6):
+            keys[row.tobytes()] = True
+    got = torch.cat([S, A, R[:, None], S1, M[:, None]], dim=1).cpu().numpy().round(6)
+    miss = sum(1 for row in got if row.tobytes() not in keys)
+    assert miss == 0, f"{miss} sampled rows are not recorded transitions"
+    assert S.shape == (20000, 10) and A.shape == (20000, 2) and M.min() >= 0 and M.max() <= 1
+    env.close()
