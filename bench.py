@@ -94,6 +94,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--world", choices=("multi", "uw"), default="multi",
+                    help="multi: MultiUAVWorld2D (headline); uw: UAVWorld2D (single UAV, BASELINE configs[1] family)")
+    ap.add_argument("--fused", action="store_true",
+                    help="multi only: drive uavx_step_ex (polar action conversion, agent0-done auto-reset with a "
+                         "1500-step cap, episode statistics) instead of the bare step")
     ap.add_argument("--mode", choices=("graph", "launch"), default="graph",
                     help="graph: steps replayed from a captured hipGraph (one kernel node per step); "
                          "launch: one ctypes->hipLaunchKernel per step")
@@ -124,14 +129,29 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D
+    from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D, BatchedUAVWorld2D
     from gym_uav_collision_avoidance_amd.sharding import gather_episode_metrics, summarize_metrics
 
     E, N, K, W = args.envs, args.agents, args.steps, args.warmup
-    env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, env_offset=rank * E, seed=0)
-    env.reset()
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    ring = polar_actions(gen, (args.ring, E, N), float(np.sqrt(200.0)), device)
+    if args.world == "uw":
+        N = 1
+        env = BatchedUAVWorld2D(E, device=device, env_offset=rank * E, seed=0)
+        ring = polar_actions(gen, (args.ring, E), float(np.sqrt(288.0)), device)  # ||(12,12)||, test_sac.py:77
+        step = env.step
+        bytes_per_env_step, kernel_name = 93, "uavx::uw_step_kernel<false>"
+    else:
+        env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, env_offset=rank * E, seed=0)
+        bytes_per_env_step = algorithmic_bytes_per_env_step(N)
+        if args.fused:
+            ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
+            step = lambda a: env.step_ex(a, polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
+            kernel_name = f"uavx::step_ex_kernel<{N if N in (1, 2, 4, 8) else 0},false>"
+        else:
+            ring = polar_actions(gen, (args.ring, E, N), float(np.sqrt(200.0)), device)
+            step = env.step
+            kernel_name = f"uavx::step_kernel<{N if N in (1, 2, 4, 8) else 0},false>"
+    env.reset()
 
     R = args.ring
     if args.mode == "graph":
@@ -140,27 +160,27 @@ def main():
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for i in range(3):
-                env.step(ring[i % R])
+                step(ring[i % R])
         torch.cuda.current_stream(device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for i in range(R):
-                env.step(ring[i])
+                step(ring[i])
 
         def run(nsteps):
             full, rem = divmod(nsteps, R)
             for _ in range(full):
                 graph.replay()
             for i in range(rem):
-                env.step(ring[i])
+                step(ring[i])
     else:
         def run(nsteps):
             for i in range(nsteps):
-                env.step(ring[i % R])
+                step(ring[i % R])
 
     run(W)
     if distributed:
-        gather_episode_metrics(env.metrics(), dst=0)  # communicator / buffers set up outside the timed region
+        gather_episode_metrics(env.metrics() if args.world == "multi" else env.get_state()["counters"], dst=0)  # warm the communicator
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -170,7 +190,7 @@ def main():
     ev0.record()
     run(K)
     ev1.record()
-    counters = env.metrics()
+    counters = env.metrics() if args.world == "multi" else env.get_state()["counters"]
     gathered = gather_episode_metrics(counters, dst=0) if distributed else counters
     torch.cuda.synchronize(device)
     if distributed:
@@ -187,26 +207,31 @@ def main():
     if rank == 0:
         total_envs = E * world
         value = total_envs * K / elapsed
-        bytes_per_launch = algorithmic_bytes_per_env_step(N) * E
+        bytes_per_launch = bytes_per_env_step * E
         kernel_s = dev_ms * 1e-3 / K  # average per-step device time over the timed region
         achieved = bytes_per_launch / kernel_s / 1e9
-        summ = summarize_metrics(gathered, N)
-        traffic = measured_traffic(E, N)
+        summ = summarize_metrics(gathered, N) if args.world == "multi" else {"mean_steps": float(gathered[:, 0].double().mean())}
+        if args.fused:
+            summ["ended_episodes"] = env.evaluation_summary()
+        traffic = measured_traffic(E, N) if (args.world == "multi" and not args.fused) else None
+        world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
+        cfg_tag = "BASELINE.json configs[2]" if (args.world == "multi" and E == 65536 and N == 4) else "non-headline size"
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (positions/obs) + f64 (velocity)", "data": "synthetic",
-            "config": {"workload": f"{E} envs x {N} UAVs per GPU (BASELINE.json configs[2]), MultiUAVWorld2D defaults, "
-                                   f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={args.mode}",
+            "config": {"workload": f"{E} envs x {N} UAVs per GPU ({cfg_tag}), {world_name} defaults, "
+                                   f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={args.mode}"
+                                   + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else ""),
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-index shard x{world}", "mode": args.mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
-                         "kernel": "uavx::step_kernel<4,false>"},
+                         "kernel": kernel_name},
             "episode_metrics": summ,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.world == "multi":
             line["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(line), flush=True)
     env.close()
