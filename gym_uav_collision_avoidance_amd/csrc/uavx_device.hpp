@@ -113,6 +113,21 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 __device__ __forceinline__ double bits53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
+// One candidate point of the multi-agent reset: counter word 1 carries (global env >> 32) in its low 16
+// bits, the agent index in bits 16..23 and the kind (0 start point, 1 target) in bits 24..31; word 2 is the
+// attempt index of that agent's rejection loop, word 3 the env's episode index.  Every agent thus owns
+// an independent candidate sequence, which lets the lanes of an env draw in parallel while the
+// accept/reject chain (MUW:127-153) stays sequential in agent order.
+__device__ __forceinline__ void reset_candidate(uint64_t global_env, uint32_t agent, uint32_t kind, uint32_t attempt,
+                                                uint32_t episode, uint32_t k0, uint32_t k1, double lox, double loy,
+                                                double hix, double hiy, float &px, float &py) {
+    uint32_t o[4];
+    const uint32_t w1 = ((uint32_t)(global_env >> 32) & 0xFFFFu) | (agent << 16) | (kind << 24);
+    philox4x32((uint32_t)global_env, w1, attempt, episode, k0, k1, o);
+    px = (float)(lox + (hix - lox) * bits53(o[0], o[1]));   // np.random.uniform(lo, hi).astype(float32)
+    py = (float)(loy + (hiy - loy) * bits53(o[2], o[3]));
+}
+
 struct PhiloxDraws {
     uint32_t env_lo, env_hi, episode, k0, k1, draw;
     // lo + (hi-lo)*U cast to float32, per axis, like np.random.uniform(...).astype(np.float32)

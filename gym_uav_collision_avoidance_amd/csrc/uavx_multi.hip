@@ -399,69 +399,76 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
-// Start/target layout of one env with the reference's rejection rules (MUW:126-153); `st` abstracts where
-// the points live (global arrays for reset_kernel, an LDS row for the in-step auto-reset).
-template <class Store>
-__device__ __forceinline__ void sample_layout(const MultiParams &p, PhiloxDraws &rng, int N, Store st) {
-    for (int i = 0; i < N; i++) {  // MUW:126-137
-        float x, y;
-        bool replicated = true;
-        while (replicated) {
-            rng.point32(p.lox, p.loy, p.hix, p.hiy, x, y);
-            replicated = false;
-            for (int j = 0; j < i; j++) {
-                const float2 o = st.loc(j);
-                if (norm32(o.x - x, o.y - y) <= p.two_r_reset) { replicated = true; break; }  // MUW:135
-            }
-        }
-        st.set_loc(i, x, y);
+// MUW:116-155 for the envs of this wave flagged `go` (all lanes of an env agree), wave-cooperative:
+// every lane draws its agent's first start/target candidates in parallel, then the accept/reject
+// chain runs in agent order through the env's LDS row {x, y, tx, ty} (a lane redraws only on a
+// clash, ~1 % of the time).  Same distribution as the reference's sequential loops; the stream
+// layout is defined by reset_candidate() and restated in oracle/uavx_oracle.c.
+template <int NT>
+__device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, Lds &lds, bool go,
+                                                uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s) {
+    const int N = NT ? NT : p.N;
+    float4 *row = &lds.pos[m.wib][m.base];
+    const uint64_t ge = (uint64_t)p.env_offset + m.e;
+    float cx = 0.f, cy = 0.f, tx = 0.f, ty = 0.f;
+    uint32_t ka = 0, kt = 0;
+    if (go) {
+        reset_candidate(ge, m.i, 0u, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, cx, cy);
+        reset_candidate(ge, m.i, 1u, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, tx, ty);
     }
-    for (int i = 0; i < N; i++) {  // MUW:140-153
-        const float2 me = st.loc(i);
-        float tx, ty;
-        bool replicated = true;
-        while (replicated) {
-            rng.point32(p.lox, p.loy, p.hix, p.hiy, tx, ty);
-            replicated = norm32(tx - me.x, ty - me.y) <= p.two_r_reset;  // MUW:146
-            for (int j = 0; j < i && !replicated; j++) {
-                const float2 o = st.tgt(j);
-                if (norm32(o.x - tx, o.y - ty) <= p.two_r_reset) replicated = true;  // MUW:151
+    for (int turn = 0; turn < N; turn++) {  // start points, MUW:126-137
+        if (go && m.i == turn) {
+            bool clash = true;
+            while (clash) {
+                clash = false;
+                for (int j = 0; j < turn && !clash; j++) {
+                    const float4 o = row[j];
+                    clash = norm32(o.x - cx, o.y - cy) <= p.two_r_reset;  // MUW:135
+                }
+                if (clash) reset_candidate(ge, m.i, 0u, ++ka, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, cx, cy);
             }
+            row[turn].x = cx; row[turn].y = cy;
         }
-        st.set_tgt(i, tx, ty);
+        wave_lds_sync();
+    }
+    for (int turn = 0; turn < N; turn++) {  // targets, MUW:140-153
+        if (go && m.i == turn) {
+            bool clash = true;
+            while (clash) {
+                clash = norm32(tx - cx, ty - cy) <= p.two_r_reset;        // MUW:146
+                for (int j = 0; j < turn && !clash; j++) {
+                    const float4 o = row[j];
+                    clash = norm32(o.z - tx, o.w - ty) <= p.two_r_reset;  // MUW:151
+                }
+                if (clash) reset_candidate(ge, m.i, 1u, ++kt, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, tx, ty);
+            }
+            row[turn].z = tx; row[turn].w = ty;
+        }
+        wave_lds_sync();
+    }
+    if (go) {
+        s.x = cx; s.y = cy; s.tx = tx; s.ty = ty;
+        s.init_d = s.prev_d = norm32(tx - cx, ty - cy);  // MUW:154-155
+        s.vx = 0.0; s.vy = 0.0; s.flags = 0;             // MUW:120-123
     }
 }
-
-struct GlobalLayout {  // points go straight to the state arrays
-    float4 *dyn; Goal *goal;
-    __device__ float2 loc(int j) const { const float4 d = dyn[j]; return make_float2(d.x, d.y); }
-    __device__ float2 tgt(int j) const { return make_float2(goal[j].tx, goal[j].ty); }
-    __device__ void set_loc(int i, float x, float y) { dyn[i] = make_float4(x, y, 0.f, __uint_as_float(0u)); }
-    __device__ void set_tgt(int i, float x, float y) { goal[i].tx = x; goal[i].ty = y; }
-};
-struct LdsLayout {  // {x, y, tx, ty} per agent in the env's LDS row
-    float4 *row;
-    __device__ float2 loc(int j) const { return make_float2(row[j].x, row[j].y); }
-    __device__ float2 tgt(int j) const { return make_float2(row[j].z, row[j].w); }
-    __device__ void set_loc(int i, float x, float y) { row[i].x = x; row[i].y = y; }
-    __device__ void set_tgt(int i, float x, float y) { row[i].z = x; row[i].w = y; }
-};
 
 // An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation
 // loop reads (test_sac_multi.py:157,164-165) and clear the running values.  One lane per env.
 __device__ __forceinline__ void fold_episode(const MultiParams &p, uint32_t e, uint32_t steps) {
+    uint4 c = p.fin_counts[e];          // all loads first: one latency, not six
+    float2 f = p.fin_returns[e];
+    const float2 run = p.ep_run[e];
+    const uint32_t reach = p.reach[e], coll = p.coll[e], epi = p.episode[e];
     if (steps != 0) {
-        uint4 c = p.fin_counts[e];
-        c.x += 1; c.y += steps; c.z += p.reach[e]; c.w += p.coll[e];
-        p.fin_counts[e] = c;
-        const float2 run = p.ep_run[e];
-        float2 f = p.fin_returns[e];
+        c.x += 1; c.y += steps; c.z += reach; c.w += coll;
         f.x += run.x; f.y += run.y;
+        p.fin_counts[e] = c;
         p.fin_returns[e] = f;
     }
     p.ep_run[e] = make_float2(0.f, 0.f);
     p.reach[e] = 0; p.coll[e] = 0;  // MUW:167-168
-    p.episode[e] += 1;
+    p.episode[e] = epi + 1;
     p.pending[e] = 0;
 }
 
@@ -508,30 +515,24 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
     double ax = 0.0, ay = 0.0;
     uint32_t steps_v = 0;
     bool do_reset = false;
+    float2 run = make_float2(0.f, 0.f);
     if (m.active) {
         load_agent(p, m.a, s);
         load_action<ACT64>(actions, m.a, ax, ay);
         if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
         do_reset = p.pending[m.e] != 0;
         steps_v = p.steps[m.e];
+        if (x.track_returns && m.i == 0) run = p.ep_run[m.e];  // issued with the other loads, used at the end
     }
     if (__ballot(do_reset) != 0ull) {  // wave-uniform: at least one env of this wave starts a new episode
-        if (do_reset && m.i == 0) {    // the env's first lane draws the layout into the env's LDS row (MUW:126-153)
-            const uint64_t ge = (uint64_t)p.env_offset + m.e;
-            PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[m.e], x.seed_lo, x.seed_hi, 0u};
-            sample_layout(p, rng, N, LdsLayout{&lds.pos[m.wib][m.base]});
-            fold_episode(p, m.e, steps_v);
-        }
-        wave_lds_sync();
+        const uint32_t episode = do_reset ? p.episode[m.e] : 0u;
+        reset_envs_wave<NT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, s);
         if (do_reset) {
-            const float4 q = lds.pos[m.wib][m.lane];
-            s.x = q.x; s.y = q.y; s.tx = q.z; s.ty = q.w;
-            s.init_d = s.prev_d = norm32(s.tx - s.x, s.ty - s.y);  // MUW:154-155
-            s.vx = 0.0; s.vy = 0.0; s.flags = 0;                   // MUW:120-123
             p.goal[m.a] = Goal{s.tx, s.ty, s.init_d};
+            if (m.i == 0) fold_episode(p, m.e, steps_v);
             steps_v = 0;                                           // MUW:166
+            run = make_float2(0.f, 0.f);
         }
-        wave_lds_sync();
     }
     float o[10], rew;
     uint32_t dn, re, ce;
@@ -560,7 +561,6 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
             p.pending[m.e] = ended ? 1 : 0;
             if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
             if (x.track_returns) {
-                float2 run = p.ep_run[m.e];
                 float score = 0.f;
                 for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.base + j];
                 run.x += do_reset ? 0.f : rew;               // test_sac_multi.py:106 score += rewards[0]
@@ -635,27 +635,25 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *_
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
-// MUW:116-168 — one lane per env (the rejection loops are sequential inside an env and reset is off
-// the per-step path); draws come from Philox keyed by (seed; global env, draw, episode).
+// MUW:116-168 for the masked envs, same lane-per-agent mapping and sampler as the in-step auto-reset.
+template <int NT>
 __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint8_t *__restrict__ mask, uint64_t seed) {
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= p.E) return;
-    if (mask && !mask[e]) return;
-    const int N = p.N;
-    const uint64_t ge = (uint64_t)(p.env_offset + e);
-    PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[e], (uint32_t)seed, (uint32_t)(seed >> 32), 0u};
-    float4 *dyn = p.dyn + e * N;
-    Goal *goal = p.goal + e * N;
-    sample_layout(p, rng, N, GlobalLayout{dyn, goal});
-    for (int i = 0; i < N; i++) {
-        const float4 me = dyn[i];
-        const float d0 = norm32(goal[i].tx - me.x, goal[i].ty - me.y);  // MUW:154
-        goal[i].init_d = d0;
-        dyn[i] = make_float4(me.x, me.y, d0, __uint_as_float(0u));       // MUW:155, MUW:122-123
-        p.vel[e * N + i] = make_double2(0.0, 0.0);                        // MUW:120
+    __shared__ Lds lds;
+    const LaneMap m = lane_map<NT>(p);
+    const bool go = m.active && (!mask || mask[m.e] != 0);
+    if (__ballot(go) == 0ull) return;
+    AgentRegs s = {};
+    const uint32_t episode = go ? p.episode[m.e] : 0u;
+    reset_envs_wave<NT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
+    if (go) {
+        p.dyn[m.a] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(0u));
+        p.vel[m.a] = make_double2(0.0, 0.0);
+        p.goal[m.a] = Goal{s.tx, s.ty, s.init_d};
+        if (m.i == 0) {
+            fold_episode(p, m.e, p.steps[m.e]);
+            p.steps[m.e] = 0;  // MUW:166
+        }
     }
-    fold_episode(p, (uint32_t)e, p.steps[e]);
-    p.steps[e] = 0;  // MUW:166
 }
 
 __global__ __launch_bounds__(kBlock) void episode_stats_kernel(MultiParams p, uint32_t *counts, float *returns, int clear) {
@@ -969,8 +967,14 @@ int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, v
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 15u))
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_reset: obs not 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((h->p.E + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(reset_kernel, grid, dim3(kBlock), 0, st, h->p, mask, seed);
+    const dim3 grid = wave_grid(h);
+    switch (h->p.N) {
+        case 1: hipLaunchKernelGGL((reset_kernel<1>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        case 2: hipLaunchKernelGGL((reset_kernel<2>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        case 4: hipLaunchKernelGGL((reset_kernel<4>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        case 8: hipLaunchKernelGGL((reset_kernel<8>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        default: hipLaunchKernelGGL((reset_kernel<0>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+    }
     UAVX_HIP(h, hipGetLastError());
     if (obs) return launch_observe(h, obs, st);
     return UAVX_OK;

@@ -110,11 +110,18 @@ void uavo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* A draw source yields pairs of U[0,1) doubles in the order np.random.uniform(lo,hi,(2,)) would. */
+/* A draw source yields pairs of U[0,1) doubles.  MT path: the process-global stream in the order
+ * np.random.uniform(lo,hi,(2,)) consumes it (the reference).  Philox path (the device resets):
+ *  - `addressed` == 0 (UAVWorld2D): counter (env_lo, env_hi, running draw index, episode);
+ *  - `addressed` == 1 (MultiUAVWorld2D): every agent owns a candidate sequence, counter
+ *    (env_lo, env_hi[15:0] | agent << 16 | kind << 24, attempt, episode), kind 0 = start, 1 = target,
+ *    so the device can draw the agents of an env in parallel (uavx_device.hpp reset_candidate()). */
 typedef struct {
     uavo_mt *mt;          /* MT path */
     uint32_t key[2];      /* Philox path */
     uint32_t ctr_env[2], episode, draw;
+    int addressed;
+    uint32_t agent, kind, attempt;
 } draw_src;
 
 static void draw_pair(draw_src *s, double u[2]) {
@@ -123,10 +130,18 @@ static void draw_pair(draw_src *s, double u[2]) {
         u[1] = uavo_mt_double(s->mt);
     } else {
         uint32_t ctr[4] = {s->ctr_env[0], s->ctr_env[1], s->draw++, s->episode}, o[4];
+        if (s->addressed) {
+            ctr[1] = (s->ctr_env[1] & 0xFFFFu) | (s->agent << 16) | (s->kind << 24);
+            ctr[2] = s->attempt++;
+        }
         uavo_philox4x32(ctr, s->key, o);
         u[0] = bits53(o[0], o[1]);
         u[1] = bits53(o[2], o[3]);
     }
+}
+/* positions the addressed Philox source at the first candidate of (agent, kind); no-op for MT */
+static void draw_begin(draw_src *s, uint32_t agent, uint32_t kind) {
+    s->agent = agent; s->kind = kind; s->attempt = 0;
 }
 /* np.random.uniform(low, high, (2,)).astype(np.float32): low + (high-low)*random_sample, then cast */
 static void draw_point32(draw_src *s, double lox, double loy, double hix, double hiy, double p[2]) {
@@ -225,9 +240,11 @@ static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_sr
     for (int i = 0; i < n; i++) { vel[2 * i] = vel[2 * i + 1] = 0.0; flags[i] = 0; } /* MUW:118-123 */
     st->f64pos[e] = 0;
 
+    draw_begin(src, 0, 0);
     draw_point32(src, lox, loy, hix, hiy, loc);                        /* MUW:126 */
     for (int i = 1; i < n; i++) {                                      /* MUW:127-137 */
         int replicated = 1;
+        draw_begin(src, (uint32_t)i, 0);
         while (replicated) {
             draw_point32(src, lox, loy, hix, hiy, loc + 2 * i);
             replicated = 0;
@@ -241,6 +258,7 @@ static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_sr
     }
     for (int i = 0; i < n; i++) {                                      /* MUW:140-155 */
         int replicated = 1;
+        draw_begin(src, (uint32_t)i, 1);
         while (replicated) {
             draw_point32(src, lox, loy, hix, hiy, tgt + 2 * i);
             replicated = 0;
@@ -290,6 +308,7 @@ void uavo_reset_philox(const uavo_config *cfg, uavo_state *st, const uint8_t *ma
         s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
         s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
         s.episode = st->counters[e * 4 + 3];
+        s.addressed = 1;
         reset_env(cfg, st, e, &s, 0);
         st->counters[e * 4 + 3] += 1; /* next reset of this env draws a fresh layout */
     }
@@ -456,6 +475,7 @@ void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep
             s.key[0] = (uint32_t)opt->seed; s.key[1] = (uint32_t)(opt->seed >> 32);
             s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
             s.episode = c[3];
+            s.addressed = 1;
             uavo_fold_episode(st, ep, e);
             reset_env(cfg, st, e, &s, 0);
             c[3] += 1;
