@@ -113,19 +113,40 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 __device__ __forceinline__ double bits53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
-// One candidate point of the multi-agent reset: counter word 1 carries (global env >> 32) in its low 16
-// bits, the agent index in bits 16..23 and the kind (0 start point, 1 target) in bits 24..31; word 2 is the
-// attempt index of that agent's rejection loop, word 3 the env's episode index.  Every agent thus owns
-// an independent candidate sequence, which lets the lanes of an env draw in parallel while the
-// accept/reject chain (MUW:127-153) stays sequential in agent order.
-__device__ __forceinline__ void reset_candidate(uint64_t global_env, uint32_t agent, uint32_t kind, uint32_t attempt,
-                                                uint32_t episode, uint32_t k0, uint32_t k1, double lox, double loy,
-                                                double hix, double hiy, float &px, float &py) {
-    uint32_t o[4];
-    const uint32_t w1 = ((uint32_t)(global_env >> 32) & 0xFFFFu) | (agent << 16) | (kind << 24);
-    philox4x32((uint32_t)global_env, w1, attempt, episode, k0, k1, o);
-    px = (float)(lox + (hix - lox) * bits53(o[0], o[1]));   // np.random.uniform(lo, hi).astype(float32)
-    py = (float)(loy + (hiy - loy) * bits53(o[2], o[3]));
+// Candidates of the multi-agent reset.  Agent i of an env owns the Philox sequence with counter
+// (global env [31:0], global env [47:32] | i << 16, attempt k, episode); call k yields the k-th START
+// candidate from words 0,1 and the k-th TARGET candidate from words 2,3 (32-bit uniforms: 1e-8 m
+// granularity over a 50 m box, far below float32 resolution).  Independent per-agent sequences let
+// the lanes of an env draw in parallel while the accept/reject chain (MUW:127-153) keeps agent order.
+// The reset path runs in a few waves per launch only, so its instructions are never warm in the
+// instruction cache: code SIZE is what it costs (measured: an unrolled, 3x-inlined version added 3.6 us
+// of tail to a 7 us step launch with 0.2 % of the envs resetting).  Hence rolled rounds; and inlined, because a
+// real call makes the callee wait for vmcnt(0), i.e. for every load the wave still has in flight.
+struct ResetCandidates {
+    float sx, sy, tx, ty;
+};
+__device__ __forceinline__ ResetCandidates reset_candidates(uint64_t global_env, uint32_t agent, uint32_t attempt,
+                                                            uint32_t episode, uint32_t k0, uint32_t k1, double lox,
+                                                            double loy, double hix, double hiy) {
+    uint32_t c0 = (uint32_t)global_env, c1 = ((uint32_t)(global_env >> 32) & 0xFFFFu) | (agent << 16);
+    uint32_t c2 = attempt, c3 = episode;
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {  // Philox4x32-10, same rounds as philox4x32() above
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t o[4] = {c0, c1, c2, c3};
+    const double sx = hix - lox, sy = hiy - loy, inv = 1.0 / 4294967296.0;
+    ResetCandidates c;  // lo + (hi-lo)*U cast to float32 like np.random.uniform(lo, hi).astype(np.float32)
+    c.sx = (float)(lox + sx * ((double)o[0] * inv));
+    c.sy = (float)(loy + sy * ((double)o[1] * inv));
+    c.tx = (float)(lox + sx * ((double)o[2] * inv));
+    c.ty = (float)(loy + sy * ((double)o[3] * inv));
+    return c;
 }
 
 struct PhiloxDraws {

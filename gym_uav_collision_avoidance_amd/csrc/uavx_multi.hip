@@ -399,76 +399,100 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
-// MUW:116-155 for the envs of this wave flagged `go` (all lanes of an env agree), wave-cooperative:
-// every lane draws its agent's first start/target candidates in parallel, then the accept/reject
-// chain runs in agent order through the env's LDS row {x, y, tx, ty} (a lane redraws only on a
-// clash, ~1 % of the time).  Same distribution as the reference's sequential loops; the stream
-// layout is defined by reset_candidate() and restated in oracle/uavx_oracle.c.
+// MUW:116-155 for the envs of this wave flagged `go` (all lanes of an env agree), wave-cooperative.
+// Every lane draws its agent's first start/target candidates with ONE Philox call; if no candidate
+// of the wave clashes with a lower-indexed one (the common case: a clash has probability ~N^2*pi*R^2
+// per box area) all are accepted at once, which is exactly what the reference's sequential
+// accept/reject loops (MUW:127-153) would do.  Otherwise the chain runs in agent order through the
+// env's LDS row {x, y, tx, ty}, each lane redrawing from its own sequence on a clash.  Same
+// distribution as the reference; stream layout: reset_candidates(), restated by the CPU test oracle.
+// ||a - b|| <= float32(2R) on the squared distance (exact: sqrtf is monotone, limit from sq_limit_le)
+__device__ __forceinline__ bool too_close(const MultiParams &p, float ax, float ay, float bx, float by) {
+    const float dx = ax - bx, dy = ay - by;
+    const float xx = dx * dx, yy = dy * dy;
+    return xx + yy <= p.sq_two_r;
+}
+
 template <int NT>
 __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, Lds &lds, bool go,
                                                 uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s) {
     const int N = NT ? NT : p.N;
     float4 *row = &lds.pos[m.wib][m.base];
     const uint64_t ge = (uint64_t)p.env_offset + m.e;
-    float cx = 0.f, cy = 0.f, tx = 0.f, ty = 0.f;
-    uint32_t ka = 0, kt = 0;
+    ResetCandidates c = {0.f, 0.f, 0.f, 0.f};
     if (go) {
-        reset_candidate(ge, m.i, 0u, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, cx, cy);
-        reset_candidate(ge, m.i, 1u, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, tx, ty);
+        c = reset_candidates(ge, m.i, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy);
+        lds.pos[m.wib][m.lane] = make_float4(c.sx, c.sy, c.tx, c.ty);
     }
-    for (int turn = 0; turn < N; turn++) {  // start points, MUW:126-137
-        if (go && m.i == turn) {
-            bool clash = true;
-            while (clash) {
-                clash = false;
-                for (int j = 0; j < turn && !clash; j++) {
-                    const float4 o = row[j];
-                    clash = norm32(o.x - cx, o.y - cy) <= p.two_r_reset;  // MUW:135
-                }
-                if (clash) reset_candidate(ge, m.i, 0u, ++ka, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, cx, cy);
-            }
-            row[turn].x = cx; row[turn].y = cy;
-        }
-        wave_lds_sync();
-    }
-    for (int turn = 0; turn < N; turn++) {  // targets, MUW:140-153
-        if (go && m.i == turn) {
-            bool clash = true;
-            while (clash) {
-                clash = norm32(tx - cx, ty - cy) <= p.two_r_reset;        // MUW:146
-                for (int j = 0; j < turn && !clash; j++) {
-                    const float4 o = row[j];
-                    clash = norm32(o.z - tx, o.w - ty) <= p.two_r_reset;  // MUW:151
-                }
-                if (clash) reset_candidate(ge, m.i, 1u, ++kt, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy, tx, ty);
-            }
-            row[turn].z = tx; row[turn].w = ty;
-        }
-        wave_lds_sync();
-    }
+    wave_lds_sync();
+    bool clash = false;
     if (go) {
-        s.x = cx; s.y = cy; s.tx = tx; s.ty = ty;
-        s.init_d = s.prev_d = norm32(tx - cx, ty - cy);  // MUW:154-155
-        s.vx = 0.0; s.vy = 0.0; s.flags = 0;             // MUW:120-123
+        clash = too_close(p, c.tx, c.ty, c.sx, c.sy);                                        // MUW:146
+#pragma unroll 1
+        for (int j = 0; j < m.i; j++) {
+            const float4 o = row[j];
+            clash = clash || too_close(p, o.x, o.y, c.sx, c.sy) || too_close(p, o.z, o.w, c.tx, c.ty);  // MUW:135,151
+        }
+    }
+    if (__ballot(clash) != 0ull) {  // rare: replay the chain sequentially, redrawing on clashes
+        wave_lds_sync();
+        uint32_t att[2] = {0u, 0u};
+#pragma unroll 1
+        for (int phase = 0; phase < 2; phase++) {      // 0: start points MUW:126-137, 1: targets MUW:140-153
+#pragma unroll 1
+            for (int turn = 0; turn < N; turn++) {
+                if (go && m.i == turn) {
+                    bool bad = true;
+                    while (bad) {
+                        const float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
+                        bad = phase ? too_close(p, qx, qy, c.sx, c.sy) : false;              // MUW:146
+#pragma unroll 1
+                        for (int j = 0; j < turn && !bad; j++) {
+                            const float4 o = row[j];
+                            bad = too_close(p, phase ? o.z : o.x, phase ? o.w : o.y, qx, qy);  // MUW:135,151
+                        }
+                        if (bad) {
+                            const ResetCandidates r = reset_candidates(ge, m.i, ++att[phase], episode, k0, k1, p.lox,
+                                                                       p.loy, p.hix, p.hiy);
+                            if (phase) { c.tx = r.tx; c.ty = r.ty; } else { c.sx = r.sx; c.sy = r.sy; }
+                        }
+                    }
+                    if (phase) { row[turn].z = c.tx; row[turn].w = c.ty; } else { row[turn].x = c.sx; row[turn].y = c.sy; }
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+    wave_lds_sync();
+    if (go) {
+        s.x = c.sx; s.y = c.sy; s.tx = c.tx; s.ty = c.ty;
+        s.init_d = s.prev_d = norm32(c.tx - c.sx, c.ty - c.sy);  // MUW:154-155
+        s.vx = 0.0; s.vy = 0.0; s.flags = 0;                      // MUW:120-123
     }
 }
 
 // An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation
 // loop reads (test_sac_multi.py:157,164-165) and clear the running values.  One lane per env.
-__device__ __forceinline__ void fold_episode(const MultiParams &p, uint32_t e, uint32_t steps) {
-    uint4 c = p.fin_counts[e];          // all loads first: one latency, not six
-    float2 f = p.fin_returns[e];
-    const float2 run = p.ep_run[e];
-    const uint32_t reach = p.reach[e], coll = p.coll[e], epi = p.episode[e];
+struct EpisodeFold {
+    uint4 c; float2 f, run; uint32_t reach, coll;
+};
+__device__ __forceinline__ EpisodeFold fold_load(const MultiParams &p, uint32_t e) {  // all loads up front: one latency
+    EpisodeFold v;
+    v.c = p.fin_counts[e]; v.f = p.fin_returns[e]; v.run = p.ep_run[e];
+    v.reach = p.reach[e]; v.coll = p.coll[e];
+    return v;
+}
+__device__ __forceinline__ void fold_store(const MultiParams &p, uint32_t e, uint32_t steps, uint32_t episode,
+                                           EpisodeFold v) {
     if (steps != 0) {
-        c.x += 1; c.y += steps; c.z += reach; c.w += coll;
-        f.x += run.x; f.y += run.y;
-        p.fin_counts[e] = c;
-        p.fin_returns[e] = f;
+        v.c.x += 1; v.c.y += steps; v.c.z += v.reach; v.c.w += v.coll;
+        v.f.x += v.run.x; v.f.y += v.run.y;
+        p.fin_counts[e] = v.c;
+        p.fin_returns[e] = v.f;
     }
     p.ep_run[e] = make_float2(0.f, 0.f);
     p.reach[e] = 0; p.coll[e] = 0;  // MUW:167-168
-    p.episode[e] = epi + 1;
+    p.episode[e] = episode + 1;
     p.pending[e] = 0;
 }
 
@@ -502,6 +526,14 @@ __device__ __forceinline__ void polar_to_command(const MultiParams &p, float a0,
     ay = (double)(v * sn);
 }
 
+#ifdef UAVX_STAMPS
+__device__ unsigned long long g_stamps[8 * 4096];
+__device__ unsigned int g_stamp_n;
+#define STAMP(k) do { if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k)
+#endif
+
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
 // episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
 template <int NT, bool ACT64>
@@ -511,32 +543,60 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
     __shared__ Lds lds;
     const int N = NT ? NT : p.N;
     const LaneMap m = lane_map<NT>(p);
+#ifdef UAVX_STAMPS
+    unsigned long long stamps[8] = {};
+    const bool stamp_on = true;
+    STAMP(0);
+#endif
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
-    uint32_t steps_v = 0;
+    uint32_t steps_v = 0, episode = 0;
     bool do_reset = false;
     float2 run = make_float2(0.f, 0.f);
+    // The per-env words are loaded FIRST and the 52 B of agent state after them: vmcnt retires in issue
+    // order, so the (rare) re-initialisation below can start as soon as the small loads are back and runs
+    // underneath the state loads of the launch-wide read burst instead of extending the wave's tail.
     if (m.active) {
-        load_agent(p, m.a, s);
-        load_action<ACT64>(actions, m.a, ax, ay);
-        if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
         do_reset = p.pending[m.e] != 0;
         steps_v = p.steps[m.e];
-        if (x.track_returns && m.i == 0) run = p.ep_run[m.e];  // issued with the other loads, used at the end
+        episode = p.episode[m.e];
+        if (x.track_returns && m.i == 0) run = p.ep_run[m.e];
     }
-    if (__ballot(do_reset) != 0ull) {  // wave-uniform: at least one env of this wave starts a new episode
-        const uint32_t episode = do_reset ? p.episode[m.e] : 0u;
-        reset_envs_wave<NT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, s);
+    __builtin_amdgcn_sched_barrier(0);
+    AgentRegs ld = {};
+    if (m.active) {
+        load_agent(p, m.a, ld);
+        load_action<ACT64>(actions, m.a, ax, ay);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    AgentRegs fresh = {};
+    EpisodeFold fold = {};
+    const uint32_t ended_steps = steps_v;
+    const bool wave_resets = __ballot(do_reset) != 0ull;
+    STAMP(1);
+    if (wave_resets) {  // wave-uniform: at least one env of this wave starts a new episode
+        // the statistics words are requested here and consumed after the step (fold_store at the end), so
+        // their round trip overlaps the step arithmetic instead of stalling this wave
+        // A wave that re-initialises an env has ~400 more instructions to issue than its three SIMD
+        // mates and would finish last (launch time = slowest wave): let it issue ahead of them for the
+        // rest of its life; the mates lose only issue slots they had to spare.
+        __builtin_amdgcn_s_setprio(3);
+        if (do_reset && m.i == 0) fold = fold_load(p, m.e);
+        reset_envs_wave<NT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, fresh);
         if (do_reset) {
-            p.goal[m.a] = Goal{s.tx, s.ty, s.init_d};
-            if (m.i == 0) fold_episode(p, m.e, steps_v);
+            p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d};
             steps_v = 0;                                           // MUW:166
             run = make_float2(0.f, 0.f);
         }
     }
+    STAMP(2);
+    s = do_reset ? fresh : ld;
+    STAMP(3);
+    if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
     float o[10], rew;
     uint32_t dn, re, ce;
     step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset);
+    STAMP(4);
     // episode end test for the NEXT call (test_sac_multi.py:67,112,116)
     const unsigned long long done_bits = __ballot(dn != 0);
     const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
@@ -560,6 +620,9 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
             p.steps[m.e] = steps_next;
             p.pending[m.e] = ended ? 1 : 0;
             if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
+            if (do_reset) {  // fold the ended episode; pending/ep_run written below supersede fold_store's
+                fold_store(p, m.e, ended_steps, episode, fold);
+            }
             if (x.track_returns) {
                 float score = 0.f;
                 for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.base + j];
@@ -570,6 +633,17 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         }
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
+#ifdef UAVX_STAMPS
+    STAMP(5);
+    if (m.lane == 0 && (wave_resets || (blockIdx.x % 64 == 0 && m.wib == 0))) {
+        const unsigned int k = atomicAdd(&g_stamp_n, 1u);
+        if (k < 4096) {
+            for (int t = 0; t < 6; t++) g_stamps[8 * k + t] = stamps[t];
+            g_stamps[8 * k + 6] = wave_resets ? 1 : 0;
+            g_stamps[8 * k + 7] = blockIdx.x;
+        }
+    }
+#endif
 }
 
 // K consecutive steps per launch from an action tape (open-loop rollouts): agent state stays in
@@ -650,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
         p.vel[m.a] = make_double2(0.0, 0.0);
         p.goal[m.a] = Goal{s.tx, s.ty, s.init_d};
         if (m.i == 0) {
-            fold_episode(p, m.e, p.steps[m.e]);
+            fold_store(p, m.e, p.steps[m.e], episode, fold_load(p, m.e));
             p.steps[m.e] = 0;  // MUW:166
         }
     }
@@ -1038,6 +1112,17 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }
+
+#ifdef UAVX_STAMPS
+extern "C" int uavx_debug_stamps(unsigned long long *host_out, unsigned int *n) {  // debug builds only
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(g_stamp_n), sizeof(unsigned int));
+    hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * 4096);
+    unsigned int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_n), &zero, sizeof zero);
+    return 0;
+}
+#endif
 
 int uavx_get_episode_stats(uavx_handle *h, uint32_t *counts, float *returns, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;

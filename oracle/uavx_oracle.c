@@ -114,14 +114,15 @@ void uavo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
  * np.random.uniform(lo,hi,(2,)) consumes it (the reference).  Philox path (the device resets):
  *  - `addressed` == 0 (UAVWorld2D): counter (env_lo, env_hi, running draw index, episode);
  *  - `addressed` == 1 (MultiUAVWorld2D): every agent owns a candidate sequence, counter
- *    (env_lo, env_hi[15:0] | agent << 16 | kind << 24, attempt, episode), kind 0 = start, 1 = target,
- *    so the device can draw the agents of an env in parallel (uavx_device.hpp reset_candidate()). */
+ *    (env_lo, env_hi[15:0] | agent << 16, attempt, episode); call k gives the k-th START candidate
+ *    from words 0,1 and the k-th TARGET candidate from words 2,3 as 32-bit uniforms, so the device
+ *    can draw the agents of an env in parallel (uavx_device.hpp reset_candidates()). */
 typedef struct {
     uavo_mt *mt;          /* MT path */
     uint32_t key[2];      /* Philox path */
     uint32_t ctr_env[2], episode, draw;
     int addressed;
-    uint32_t agent, kind, attempt;
+    uint32_t agent, kind, attempt[2];
 } draw_src;
 
 static void draw_pair(draw_src *s, double u[2]) {
@@ -131,8 +132,12 @@ static void draw_pair(draw_src *s, double u[2]) {
     } else {
         uint32_t ctr[4] = {s->ctr_env[0], s->ctr_env[1], s->draw++, s->episode}, o[4];
         if (s->addressed) {
-            ctr[1] = (s->ctr_env[1] & 0xFFFFu) | (s->agent << 16) | (s->kind << 24);
-            ctr[2] = s->attempt++;
+            ctr[1] = (s->ctr_env[1] & 0xFFFFu) | (s->agent << 16);
+            ctr[2] = s->attempt[s->kind]++;
+            uavo_philox4x32(ctr, s->key, o);
+            u[0] = (double)o[2 * s->kind] * (1.0 / 4294967296.0);
+            u[1] = (double)o[2 * s->kind + 1] * (1.0 / 4294967296.0);
+            return;
         }
         uavo_philox4x32(ctr, s->key, o);
         u[0] = bits53(o[0], o[1]);
@@ -141,7 +146,7 @@ static void draw_pair(draw_src *s, double u[2]) {
 }
 /* positions the addressed Philox source at the first candidate of (agent, kind); no-op for MT */
 static void draw_begin(draw_src *s, uint32_t agent, uint32_t kind) {
-    s->agent = agent; s->kind = kind; s->attempt = 0;
+    s->agent = agent; s->kind = kind; s->attempt[kind] = 0;
 }
 /* np.random.uniform(low, high, (2,)).astype(np.float32): low + (high-low)*random_sample, then cast */
 static void draw_point32(draw_src *s, double lox, double loy, double hix, double hiy, double p[2]) {
