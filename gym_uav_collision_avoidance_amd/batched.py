@@ -171,6 +171,25 @@ class BatchedMultiUAVWorld2D(_Base):
         self._resets += 1
         return obs
 
+    def reset_circular(self, radius=20.0, target_radius=23.0):
+        """reset(circular=True) of the reference (MUW:157-163) for every env: UAV i starts at angle 2*pi*i/N
+        on a circle of `radius` and must reach the antipodal point on `target_radius`.  The reference keeps
+        these points in float64; device positions are float32 (DESIGN.md numerics)."""
+        import math
+        E, N = self.num_envs, self.num_agents
+        th = 2 * np.arange(N) * math.pi / N
+        loc = (radius * np.stack([np.cos(th), np.sin(th)], axis=1)).astype(np.float32)
+        tgt = (target_radius * np.stack([np.cos(th + math.pi), np.sin(th + math.pi)], axis=1)).astype(np.float32)
+        d = tgt - loc
+        init_d = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+        cnt = self.metrics().cpu().numpy().astype(np.int64)
+        cnt[:, :3] = 0
+        cnt[:, 3] += 1
+        self.set_state(loc=np.broadcast_to(loc, (E, N, 2)), tgt=np.broadcast_to(tgt, (E, N, 2)),
+                       vel=np.zeros((E, N, 2)), init_d=np.broadcast_to(init_d, (E, N)),
+                       prev_d=np.broadcast_to(init_d, (E, N)), flags=np.zeros((E, N), np.uint8), counters=cnt)
+        return self.observe()
+
     # -- MUW:177-241 -------------------------------------------------------------------------------
     def step(self, actions, evaluate=False, out=None):
         """actions: [E, N, 2] float32/float64 velocity commands.  Returns (obs [E,N,10] f32,

@@ -116,8 +116,17 @@ class MultiUAVWorld2D:
         done = done[0].cpu().numpy()
         return (self._obs_list(obs), [float(r) for r in rew], [bool(d) for d in done], self._get_info())
 
-    def render(self, mode="human"):  # MUW:243 — pygame window replaced by a no-op (headless node)
-        return None
+    def render(self, mode="human"):
+        """MUW:243-331.  mode="human" is a no-op (no display / pygame on a compute node, and the trainers call
+        it every step); mode="rgb_array" rasterises the same scene with numpy from one get_state(): targets as
+        squares, UAVs as discs with a heading tick and collider ring, agent 0's sensing ring and the lines to its
+        (up to) two nearest neighbours."""
+        if mode != "rgb_array":
+            return None
+        from .render import draw_world
+        st = {k: v[0].cpu().numpy() for k, v in self._batched.get_state().items()}
+        return draw_world(st["loc"], st["tgt"], st["vel"], [a.color for a in self.agent_list], self.x_size, self.y_size,
+                          self.collider_radius, self.d_sense)
 
     def close(self):  # MUW:333
         self._batched.close()

@@ -1,0 +1,69 @@
+"""Batched evaluation harness: the reference evaluates one episode at a time
+(test_sac_multi.py:132-183, test_sac_multi_score.py:31-80); here `episodes` worlds run side by side,
+one episode each, with the same stopping rule and the same SR / CR / score formulas."""
+import math
+
+import torch
+
+from .batched import BatchedMultiUAVWorld2D
+
+
+@torch.no_grad()
+def evaluate_policy(policy_fn, num_agents, episodes=100, max_steps=2000, evaluate=True, circular=False, seed=0,
+                    device=None, polar=True, **env_kwargs):
+    """Runs `episodes` parallel episodes of an `num_agents`-UAV world.
+
+    policy_fn(obs [E,N,10] float32 device tensor) -> actions [E,N,2]; with polar=True they are policy
+    outputs in [-1,1]^2 converted on the device like test_sac_multi_score.py:47-49, else velocity commands.
+    An episode ends when all(dones) (:59) or after max_steps (:13,41); its counters are read at that
+    moment (:63-64).  Returns dict(success_rate, collision_rate, avg_score, score0, mean_steps)."""
+    env = BatchedMultiUAVWorld2D(episodes, num_agents=num_agents, device=device, seed=seed, **env_kwargs)
+    obs = env.reset_circular() if circular else env.reset()
+    E, N, dev = episodes, num_agents, env.device
+    ended = torch.zeros(E, dtype=torch.bool, device=dev)
+    reach = torch.zeros(E, dtype=torch.int64, device=dev)
+    coll = torch.zeros(E, dtype=torch.int64, device=dev)
+    length = torch.zeros(E, dtype=torch.int64, device=dev)
+    score0 = torch.zeros(E, dtype=torch.float64, device=dev)
+    total = torch.zeros(E, dtype=torch.float64, device=dev)
+    for t in range(max_steps):
+        act = policy_fn(obs)
+        obs, rew, done, _ = env.step_ex(act, evaluate=evaluate, polar=polar, track_returns=False)
+        live = ~ended
+        score0 += torch.where(live, rew[:, 0].double(), 0.0)                                       # test_sac_multi.py:155
+        total += torch.where(live, (rew.double() * (1.0 - done.double())).sum(dim=1), 0.0)         # :157
+        newly = live & (done.all(dim=1) | (t + 1 >= max_steps))                                    # :161 / :140
+        m = env.metrics()  # snapshot at the step an env ends (ended envs keep evolving and are ignored)
+        reach = torch.where(newly, m[:, 1].long(), reach)
+        coll = torch.where(newly, m[:, 2].long(), coll)
+        length = torch.where(newly, torch.full_like(length, t + 1), length)
+        ended |= newly
+        if t % 32 == 31 and bool(ended.all()):
+            break
+    denom = N * E
+    out = dict(num_agents=N, episodes=E,
+               success_rate=float(reach.sum()) / denom,          # test_sac_multi.py:174
+               collision_rate=float(coll.sum()) / denom,         # :175
+               avg_score=float(total.sum()) / denom,             # :176
+               score0=float(score0.mean()), mean_steps=float(length.double().mean()))
+    env.close()
+    return out
+
+
+def sweep_num_agents(policy_fn, agent_counts=range(1, 25), episodes=100, max_steps=2000, **kw):
+    """SR / CR versus the number of UAVs like test_sac_multi_score.py:31-80."""
+    return [evaluate_policy(policy_fn, n, episodes=episodes, max_steps=max_steps, **kw) for n in agent_counts]
+
+
+def seek_policy(env_diag=math.hypot(50.0, 50.0), brake=2.0, vcap=8.0, vmax_norm=math.sqrt(200.0)):
+    """A hand-written goal-seeking controller expressed on the OBSERVATION (so it can drive either the
+    reference or this build): fly along the target bearing, brake with the distance.  Returns policy
+    outputs in [-1,1]^2 for the polar action convention.  Used by tests and examples."""
+    def fn(obs):
+        dist = obs[..., 2] * env_diag
+        heading = obs[..., 1] + obs[..., 3]          # (theta_v + wrap(theta_t - theta_v)) / pi
+        speed = torch.where(dist > 0.3, torch.clamp(torch.sqrt(2 * brake * dist), max=vcap), torch.zeros_like(dist))
+        a0 = (speed / vmax_norm) * 2 - 1
+        a1 = torch.remainder(heading + 1.0, 2.0) - 1.0
+        return torch.stack([a0, a1], dim=-1)
+    return fn
