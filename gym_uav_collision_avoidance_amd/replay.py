@@ -14,10 +14,12 @@ from . import _lib
 
 
 class DeviceReplay:
-    def __init__(self, env, horizon):
+    def __init__(self, env, horizon, num_learners=None):
         """env: BatchedMultiUAVWorld2D; horizon: number of most recent steps kept (capacity in
-        transitions = horizon * num_envs * num_agents)."""
+        transitions = horizon * num_envs * num_learners).  num_learners: only agents [0, num_learners)
+        are sampled (the rest are scripted bodies of the config-5 style extension); default all."""
         self.env, self.T = env, int(horizon)
+        self.num_learners = env.num_agents if num_learners is None else int(num_learners)
         L, E, N, dev = self.T + 1, env.num_envs, env.num_agents, env.device
         self.L = L
         self.obs = torch.zeros((L, E, N, _lib.OBS_DIM), dtype=torch.float32, device=dev)
@@ -28,7 +30,7 @@ class DeviceReplay:
         self.count = 0  # steps written so far
 
     def __len__(self):
-        return min(self.count, self.T) * self.env.num_envs * self.env.num_agents
+        return min(self.count, self.T) * self.env.num_envs * self.num_learners
 
     def begin(self, obs0):
         """Stores the observation the first step starts from (what env.reset() returned)."""
@@ -59,7 +61,7 @@ class DeviceReplay:
         """Uniform batch of transitions like ReplayMemory.sample (replay_memory.py:21-24):
         (state [B,10], action [B,2], reward [B], next_state [B,10], mask [B] = 1 - done).  Fixed size, no host sync."""
         assert self.count > 0
-        E, N, dev = self.env.num_envs, self.env.num_agents, self.env.device
+        E, N, dev = self.env.num_envs, self.num_learners, self.env.device
         lo = max(0, self.count - self.T)
         span = self.count - lo
 

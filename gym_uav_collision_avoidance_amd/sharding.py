@@ -53,3 +53,29 @@ def summarize_metrics(counters, num_agents):
     return dict(success_rate=float(c[:, 1].sum() / (num_agents * episodes)),
                 collision_rate=float(c[:, 2].sum() / (num_agents * episodes)),
                 mean_steps=float(c[:, 0].mean()))
+
+
+def make_sharded_env(total_envs, device=None, group=None, seed=0, **env_kwargs):
+    """This rank's shard of a `total_envs`-world job as a BatchedMultiUAVWorld2D: global env ids key the
+    Philox reset streams (env_offset), so the union of the shards equals the unsharded batch."""
+    from .batched import BatchedMultiUAVWorld2D
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    offset, count = shard_range(total_envs, world, rank)
+    return BatchedMultiUAVWorld2D(count, device=device, env_offset=offset, seed=seed, **env_kwargs)
+
+
+def gather_evaluation_summary(env, dst=0, group=None):
+    """SR / CR / score over the ended episodes of ALL shards (one gather of [E_local, 6] rows)."""
+    st = env.episode_stats()
+    rows = torch.stack([st["episodes"].float(), st["steps"].float(), st["reach"].float(), st["coll"].float(),
+                        st["return0"], st["score"]], dim=1)
+    allrows = gather_episode_metrics(rows, dst=dst, group=group)
+    if allrows is None:
+        return None
+    a = allrows.double().sum(dim=0)
+    denom = max(1.0, env.num_agents * float(a[0]))
+    return dict(episodes=int(a[0]), success_rate=float(a[2]) / denom, collision_rate=float(a[3]) / denom,
+                avg_score=float(a[5]) / denom, mean_steps=float(a[1]) / max(1.0, float(a[0])))
