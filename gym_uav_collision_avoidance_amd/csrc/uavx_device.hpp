@@ -9,7 +9,10 @@
 namespace uavx {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;               // 4 waves per workgroup
+#ifndef UAVX_BLOCK
+#define UAVX_BLOCK 64  // A/B 64..1024 on MI355X: within 2 %, 64 marginally best (single-wave workgroups)
+#endif
+constexpr int kBlock = UAVX_BLOCK;        // waves per workgroup = kBlock / 64
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kInvPi = 0.318309886183790671538f;

@@ -929,10 +929,10 @@ const char *uavx_strerror(int status) {
 int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device, uavx_handle **out) {
     if (!cfg || !out || num_envs <= 0 || env_offset < 0) return UAVX_ERR_INVALID_ARG;
     if (cfg->num_agents < 1 || cfg->num_agents > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
-    if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 26)) return UAVX_ERR_UNSUPPORTED;  // 32-bit byte offsets (obs: 40 B/agent)
     if (!(cfg->tau > 0) || !(cfg->max_speed > 0) || !(cfg->max_acceleration > 0) || !(cfg->x_size > 0) ||
         !(cfg->y_size > 0) || !(cfg->d_sense > 0) || !(cfg->collider_radius >= 0))
         return UAVX_ERR_INVALID_ARG;
+    if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 26)) return UAVX_ERR_UNSUPPORTED;  // 32-bit byte offsets (obs: 40 B/agent)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UAVX_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return UAVX_ERR_INVALID_ARG;

@@ -126,3 +126,29 @@ def test_gloo_world2_metrics_gather():
     want = np.stack([rows * 3, rows % 5, rows % 2, np.ones_like(rows)], axis=1)
     np.testing.assert_array_equal(got, want)
     assert summary["success_rate"] == pytest.approx((rows % 5).sum() / (4 * total))
+
+
+def test_abi_argument_validation_without_gpu():
+    """Status codes of the C ABI for bad arguments (checked before any device is touched) and for a
+    box without a GPU; nothing computes here."""
+    import ctypes
+    from gym_uav_collision_avoidance_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    good = _lib.Config(50.0, 50.0, 10.0, 5.0, 1.0, 15.0, 0.02, 4, 0)
+    assert L.uavx_create(None, 8, 0, 0, ctypes.byref(h)) == -1                       # NULL config
+    assert L.uavx_create(ctypes.byref(good), 0, 0, 0, ctypes.byref(h)) == -1         # no envs
+    assert L.uavx_create(ctypes.byref(good), 8, -1, 0, ctypes.byref(h)) == -1        # negative env_offset
+    for field, val in (("num_agents", 0), ("num_agents", 65), ("tau", 0.0), ("max_speed", -1.0), ("x_size", 0.0),
+                       ("d_sense", 0.0), ("collider_radius", -0.5)):
+        bad = _lib.Config(50.0, 50.0, 10.0, 5.0, 1.0, 15.0, 0.02, 4, 0)
+        setattr(bad, field, val)
+        assert L.uavx_create(ctypes.byref(bad), 8, 0, 0, ctypes.byref(h)) == -1, field
+    assert L.uavx_create(ctypes.byref(good), 1 << 24, 0, 0, ctypes.byref(h)) == -4   # E*N >= 2^26: unsupported
+    if not torch.cuda.is_available():
+        assert L.uavx_create(ctypes.byref(good), 8, 0, 0, ctypes.byref(h)) == -3     # UAVX_ERR_NO_DEVICE
+    assert L.uavx_step(None, None, 0, 0, None, None, None, None) == -1
+    assert L.uavx_destroy(None) == -1
+    assert b"null handle" in L.uavx_last_error(None)
+    uw = _lib.UWConfig(100.0, 100.0, 12.0, 5.0, 0.0)
+    assert L.uavx_uw_create(ctypes.byref(uw), 8, 0, 0, ctypes.byref(h)) == -1       # tau == 0
