@@ -18,9 +18,12 @@
 //   5. the 10 observation floats per agent are transposed through LDS so the wave writes its
 //      2560-byte obs block with 16-byte-per-lane contiguous stores.
 // HBM layout (agent slot a = e*N + i, agent fastest => lane-contiguous):
-//   dyn  float4[A]  {x, y, prev_d, flags}   read+write   16 B
-//   vel  double2[A] {vx, vy}                read+write   16 B
-//   goal float[3A]  {tx, ty, init_d}        read         12 B
+//   pos  float2[A]  {x, y}                     read+write    8 B
+//   vel  double2[A] {vx, vy}                   read+write   16 B
+//   goal float4[A]  {tx, ty, init_d, flags}    read         16 B   (flags word rewritten only when it changes)
+//   prev_distance (AG:18) is NOT stored: for an agent that is not done it always equals ||target - location||
+//   (AG:33-34, MUW:155,229), so it is recomputed from the loaded position; values a caller pokes in that
+//   break this identity live in prev_ovr[A] behind the PREVD_OVR flag bit (read only when the bit is set).
 //   per-env uint32 steps[E] (r/w by the env's first lane), reach[E] / coll[E] (atomics on the rare
 //   events), episode[E] (reset only).
 #include <hip/hip_runtime.h>
@@ -36,7 +39,13 @@
 
 namespace uavx {
 
-struct Goal { float tx, ty, init_d; };  // 12 B, read-only on the step path (one dwordx3 load)
+struct Goal { float tx, ty, init_d; uint32_t flags; };  // 16 B, one dwordx4 load; flags word stored only on change
+
+// flag bits kept in Goal::flags (bits 0,1 are the public UAVX_FLAG_DONE / UAVX_FLAG_COLLIDED)
+constexpr uint32_t kFlagPublic = UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED;
+constexpr uint32_t kFlagPrevOvr = 8u;    // prev_distance is the value in prev_ovr[a], not ||target - location||
+constexpr uint32_t kFlagJustDone = 16u;  // finished during the last step: prev_distance is still the distance then
+                                         // (MUW:229 stores it once more; from the next step on it is 0, AG:24-25)
 
 struct MultiParams {
     double tau, rtau, amax, vmax;  // rtau = RN(1/tau), see div_tau()
@@ -54,7 +63,8 @@ struct MultiParams {
     int recip_ok;         // div_tau() may use the reciprocal form for this tau
     int N, epw, magic;    // agents per env, envs per wave, ceil(65536/N)+... for lane/N
     int64_t E, env_offset;
-    float4 *dyn;
+    float2 *pos;
+    float *prev_ovr;
     double2 *vel;
     Goal *goal;
     uint32_t *steps, *reach, *coll, *episode;
@@ -125,26 +135,27 @@ struct Lds {
 
 // Agent slots are addressed with 32-bit lane offsets from scalar base pointers (saddr + voffset
 // addressing; uavx_create rejects E*N >= 2^26).
-__device__ __forceinline__ void load_agent(const MultiParams &p, uint32_t a, AgentRegs &s) {
-    const float4 d = p.dyn[a];
-    const double2 v = p.vel[a];
-    s.x = d.x; s.y = d.y; s.prev_d = d.z; s.flags = __float_as_uint(d.w);
-    s.vx = v.x; s.vy = v.y;
-    const Goal g = p.goal[a];
-    s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d;
+// prev_distance as the reference would hold it for this (flags, position, target)
+__device__ __forceinline__ float natural_prev_d(uint32_t flags, float x, float y, float tx, float ty) {
+    const float d = norm32(tx - x, ty - y);
+    return ((flags & UAVX_FLAG_DONE) && !(flags & kFlagJustDone)) ? 0.f : d;
 }
-__device__ __forceinline__ void store_agent(const MultiParams &p, uint32_t a, const AgentRegs &s) {
-#ifndef UAVX_STATE_WT
-#define UAVX_STATE_WT 0  // A/B on MI355X (65536x4): plain state stores keep dyn/vel in the XCD L2 for the next step: 6.76 vs 7.3 us
-#endif
-#if UAVX_STATE_WT
-    const uint32_t bytes = (uint32_t)p.E * (uint32_t)p.N * 16u;  // dyn and vel are both 16 B per agent
-    store16_wt(make_rsrc(p.dyn, bytes), a * 16u, make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags)));
-    store16_wt(make_rsrc(p.vel, bytes), a * 16u, make_double2(s.vx, s.vy));
-#else
-    p.dyn[a] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags));
-    p.vel[a] = make_double2(s.vx, s.vy);
-#endif
+
+__device__ __forceinline__ void load_agent(const MultiParams &p, uint32_t a, AgentRegs &s) {
+    const float2 d = p.pos[a];
+    const double2 v = p.vel[a];
+    const Goal g = p.goal[a];
+    s.x = d.x; s.y = d.y;
+    s.vx = v.x; s.vy = v.y;
+    s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d; s.flags = g.flags;
+    s.prev_d = natural_prev_d(s.flags, s.x, s.y, s.tx, s.ty);
+    if (s.flags & kFlagPrevOvr) s.prev_d = p.prev_ovr[a];  // rare: only after a caller poked the state
+}
+// flags_in: the flags word as loaded (the word is stored only if the step changed it)
+__device__ __forceinline__ void store_agent(const MultiParams &p, uint32_t a, const AgentRegs &s, uint32_t flags_in) {
+    p.pos[a] = make_float2(s.x, s.y);       // plain stores: A/B on MI355X showed write-through state stores slower
+    p.vel[a] = make_double2(s.vx, s.vy);    // (7.3 vs 6.76 us at 65536x4); only the obs tile is written sc1
+    if (s.flags != flags_in) p.goal[a].flags = s.flags;
 }
 
 // Neighbour scan of one agent over the other N-1 agents of its env (positions staged in LDS).
@@ -296,6 +307,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
                                            uint32_t &reach_ev, uint32_t &coll_ev, bool frozen = false) {
     // frozen: the env was re-initialised by this call (auto-reset); the agent only observes.
     const bool was_done = (s.flags & UAVX_FLAG_DONE) != 0;
+    if (!frozen) s.flags &= ~(kFlagPrevOvr | kFlagJustDone);  // from here on prev_distance is the natural one again
     const float ox = s.x, oy = s.y;
     float pd = 0.f, d = 0.f;  // AG:24-25: a done agent returns (0, 0) and does not move
     if (!was_done && !frozen) {
@@ -344,7 +356,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     } else if (d < 0.5f && !collision && sq < p.speed_sq_lim) {     // MUW:218
         done_out = 1;
         reach_ev = was_done ? 0u : 1u;                       // MUW:220-221
-        s.flags |= UAVX_FLAG_DONE;                           // AG:39
+        s.flags |= UAVX_FLAG_DONE | (was_done ? 0u : kFlagJustDone);  // AG:39
         const double nv = sqrt(sq);                          // AG:40
         double fx = s.vx / nv * 0.001, fy = s.vy / nv * 0.001;
         if (fx != fx || fy != fy) { fx = 0.0; fy = 0.0; }    // AG:41-42
@@ -385,11 +397,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
         load_agent(p, m.a, s);
         load_action<ACT64>(actions, m.a, ax, ay);
     }
+    const uint32_t flags_in = s.flags;
     float o[10], rew;
     uint32_t dn, re, ce;
     step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
     if (m.active) {
-        store_agent(p, m.a, s);
+        store_agent(p, m.a, s, flags_in);
         rew_out[m.a] = rew;
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
@@ -584,13 +597,14 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         if (do_reset && m.i == 0) fold = fold_load(p, m.e);
         reset_envs_wave<NT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, fresh);
         if (do_reset) {
-            p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d};
+            p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d, 0u};
             steps_v = 0;                                           // MUW:166
             run = make_float2(0.f, 0.f);
         }
     }
     STAMP(2);
     s = do_reset ? fresh : ld;
+    const uint32_t flags_in = s.flags;
     STAMP(3);
     if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
     float o[10], rew;
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         wave_lds_sync();
     }
     if (m.active) {
-        store_agent(p, m.a, s);
+        store_agent(p, m.a, s, flags_in);
         rew_out[m.a] = rew;
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
@@ -657,6 +671,7 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
     const LaneMap m = lane_map<NT>(p);
     AgentRegs s = {};
     if (m.active) load_agent(p, m.a, s);
+    const uint32_t flags_in = s.flags;
     const size_t A = (size_t)p.E * N;
     uint32_t reach_acc = 0, coll_acc = 0;
     for (int k = 0; k < K; k++) {
@@ -680,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
         }
     }
     if (m.active) {
-        store_agent(p, m.a, s);
+        store_agent(p, m.a, s, flags_in);
         if (reach_acc) atomicAdd(&p.reach[m.e], reach_acc);  // MUW:221
         if (coll_acc) atomicAdd(&p.coll[m.e], coll_acc);     // MUW:209
         if (m.i == 0) atomicAdd(&p.steps[m.e], (uint32_t)K); // MUW:238
@@ -720,9 +735,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
     const uint32_t episode = go ? p.episode[m.e] : 0u;
     reset_envs_wave<NT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
     if (go) {
-        p.dyn[m.a] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(0u));
+        p.pos[m.a] = make_float2(s.x, s.y);
         p.vel[m.a] = make_double2(0.0, 0.0);
-        p.goal[m.a] = Goal{s.tx, s.ty, s.init_d};
+        p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, 0u};
         if (m.i == 0) {
             fold_store(p, m.e, p.steps[m.e], episode, fold_load(p, m.e));
             p.steps[m.e] = 0;  // MUW:166
@@ -752,13 +767,14 @@ __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_s
     const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t A = p.E * p.N;
     if (a < A) {
-        const float4 d = p.dyn[a];
+        const float2 d = p.pos[a];
+        const Goal g = p.goal[a];
         if (v.loc) { v.loc[2 * a] = d.x; v.loc[2 * a + 1] = d.y; }
-        if (v.prev_d) v.prev_d[a] = d.z;
-        if (v.flags) v.flags[a] = (uint8_t)__float_as_uint(d.w);
+        if (v.prev_d) v.prev_d[a] = (g.flags & kFlagPrevOvr) ? p.prev_ovr[a] : natural_prev_d(g.flags, d.x, d.y, g.tx, g.ty);
+        if (v.flags) v.flags[a] = (uint8_t)(g.flags & kFlagPublic);
         if (v.vel) { const double2 w = p.vel[a]; v.vel[2 * a] = w.x; v.vel[2 * a + 1] = w.y; }
-        if (v.tgt) { v.tgt[2 * a] = p.goal[a].tx; v.tgt[2 * a + 1] = p.goal[a].ty; }
-        if (v.init_d) v.init_d[a] = p.goal[a].init_d;
+        if (v.tgt) { v.tgt[2 * a] = g.tx; v.tgt[2 * a + 1] = g.ty; }
+        if (v.init_d) v.init_d[a] = g.init_d;
     }
     if (a < p.E && v.counters) {
         v.counters[4 * a + 0] = p.steps[a]; v.counters[4 * a + 1] = p.reach[a];
@@ -766,18 +782,32 @@ __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_s
     }
 }
 
+// Overwrites any subset of the UAVAgent fields.  prev_distance keeps the VALUE the reference would hold: a
+// field the caller does not pass stays what it was (e.g. poking only .location leaves prev_distance stale,
+// test_sac_multi_plot_trajectory.py:43-49), and whenever that value is not the one derived from the new
+// (flags, location, target) it is parked in prev_ovr[] behind the PREVD_OVR bit until the next step.
 __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_state_view v) {
     const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t A = p.E * p.N;
     if (a < A) {
-        float4 d = p.dyn[a];
+        float2 d = p.pos[a];
+        Goal g = p.goal[a];
+        const float old_prev = (g.flags & kFlagPrevOvr) ? p.prev_ovr[a] : natural_prev_d(g.flags, d.x, d.y, g.tx, g.ty);
         if (v.loc) { d.x = v.loc[2 * a]; d.y = v.loc[2 * a + 1]; }
-        if (v.prev_d) d.z = v.prev_d[a];
-        if (v.flags) d.w = __uint_as_float((uint32_t)v.flags[a]);
-        p.dyn[a] = d;
+        if (v.tgt) { g.tx = v.tgt[2 * a]; g.ty = v.tgt[2 * a + 1]; }
+        if (v.init_d) g.init_d = v.init_d[a];
+        uint32_t flags = g.flags & ~kFlagPrevOvr;
+        if (v.flags) flags = (uint32_t)v.flags[a] & kFlagPublic;  // a caller-set done flag is not "just finished"
+        const float want = v.prev_d ? v.prev_d[a] : old_prev;
+        const float nat = natural_prev_d(flags, d.x, d.y, g.tx, g.ty);
+        if (__float_as_uint(want) != __float_as_uint(nat)) {
+            flags |= kFlagPrevOvr;
+            p.prev_ovr[a] = want;
+        }
+        g.flags = flags;
+        p.pos[a] = d;
+        p.goal[a] = g;
         if (v.vel) p.vel[a] = make_double2(v.vel[2 * a], v.vel[2 * a + 1]);
-        if (v.tgt) { p.goal[a].tx = v.tgt[2 * a]; p.goal[a].ty = v.tgt[2 * a + 1]; }
-        if (v.init_d) p.goal[a].init_d = v.init_d[a];
     }
     if (a < p.E && v.counters) {
         p.steps[a] = v.counters[4 * a + 0]; p.reach[a] = v.counters[4 * a + 1];
@@ -969,9 +999,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     if (e != hipSuccess) { delete h; return UAVX_ERR_HIP; }
     const size_t A = (size_t)num_envs * N, E = (size_t)num_envs;
     size_t off = 0;
-    const size_t o_dyn = off;  off = align_up(off + A * sizeof(float4), 256);
+    const size_t o_pos = off;  off = align_up(off + A * sizeof(float2), 256);
+    const size_t o_ovr = off;  off = align_up(off + A * sizeof(float), 256);
     const size_t o_vel = off;  off = align_up(off + A * sizeof(double2), 256);
-    const size_t o_goal = off; off = align_up(off + A * 3 * sizeof(float), 256);
+    const size_t o_goal = off; off = align_up(off + A * sizeof(Goal), 256);
     const size_t o_steps = off; off = align_up(off + E * 4, 256);
     const size_t o_reach = off; off = align_up(off + E * 4, 256);
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
@@ -985,7 +1016,8 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     e = hipMemset(h->slab, 0, off);
     if (e != hipSuccess) { (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP; }
     char *b = static_cast<char *>(h->slab);
-    p.dyn = reinterpret_cast<float4 *>(b + o_dyn);
+    p.pos = reinterpret_cast<float2 *>(b + o_pos);
+    p.prev_ovr = reinterpret_cast<float *>(b + o_ovr);
     p.vel = reinterpret_cast<double2 *>(b + o_vel);
     p.goal = reinterpret_cast<Goal *>(b + o_goal);
     p.steps = reinterpret_cast<uint32_t *>(b + o_steps);

@@ -368,3 +368,56 @@ def test_errors_are_loud(amd):
     with pytest.raises(ValueError):
         amd.BatchedMultiUAVWorld2D(8, num_agents=65)
     env.close()
+
+
+def test_poked_state_keeps_reference_prev_distance_semantics(amd, oracle_mod):
+    """prev_distance is not stored on the device (it is derived from position/target); values that break
+    that identity — a caller moving an agent without touching prev_distance, as
+    test_sac_multi_plot_trajectory.py:43-49 does, or setting done flags — must still act exactly like the
+    reference's explicit field for the next step."""
+    E, n = 700, 4
+    env = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=8)
+    orc = oracle_mod.OracleMulti(num_envs=E, num_agents=n, nthreads=8)
+    env.reset()
+    orc.reset_philox(8)
+    rng = np.random.default_rng(4)
+
+    def step_both(ctx):
+        act = rng.uniform(-10, 10, size=(E, n, 2)).astype(np.float32)
+        obs_g, rew_g, done_g, _ = env.step(act)
+        obs_o, rew_o, done_o = orc.step(act)
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        ref = orc.get_state()
+        _check_multi_state(env, dict(flags=ref["flags"], loc=ref["loc"], prev_d=ref["prev_d"], vel=ref["vel"],
+                                     counters=ref["counters"][:, :3]), ctx)
+        assert float(np.abs(_np(rew_g) - rew_o).max()) <= TOL and obs_err(_np(obs_g), obs_o) <= TOL, ctx
+
+    for t in range(5):
+        step_both(f"warm {t}")
+    # (1) move agents, prev_distance left stale
+    new_loc = orc.loc.copy()
+    new_loc[::2, 1] = rng.uniform(-20, 20, size=new_loc[::2, 1].shape).astype(np.float32)
+    env.set_state(loc=new_loc)
+    orc.set_state(loc=new_loc)
+    np.testing.assert_array_equal(_np(env.get_state()["prev_d"]), orc.prev_d.astype(np.float32))
+    step_both("after loc poke")
+    step_both("after loc poke +1")
+    # (2) explicit prev_distance and done flags (a done agent never moves again, AG:24-25)
+    flags = orc.flags.copy(); flags[1::3, 2] |= 1
+    pd = orc.prev_d.copy(); pd[:, 0] = 3.25
+    env.set_state(flags=flags, prev_d=pd)
+    orc.set_state(flags=flags, prev_d=pd)
+    st = env.get_state()
+    np.testing.assert_array_equal(_np(st["prev_d"]), pd.astype(np.float32))
+    np.testing.assert_array_equal(_np(st["flags"]), flags)
+    for t in range(4):
+        step_both(f"after flag/prev_d poke {t}")
+    # (3) get_state -> set_state round trip is the identity
+    st = env.get_state()
+    env.set_state(**{k: v for k, v in st.items()})
+    st2 = env.get_state()
+    import torch
+    for k in st:
+        assert torch.equal(st[k], st2[k]), k
+    step_both("after round trip")
+    env.close()
