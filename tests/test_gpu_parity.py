@@ -390,7 +390,9 @@ def test_poked_state_keeps_reference_prev_distance_semantics(amd, oracle_mod):
         ref = orc.get_state()
         _check_multi_state(env, dict(flags=ref["flags"], loc=ref["loc"], prev_d=ref["prev_d"], vel=ref["vel"],
                                      counters=ref["counters"][:, :3]), ctx)
-        assert float(np.abs(_np(rew_g) - rew_o).max()) <= TOL and obs_err(_np(obs_g), obs_o) <= TOL, ctx
+        # a teleported agent earns |reward| up to ~50 (MUW:190): beyond |r| = 1 the bar is relative (float32 output)
+        assert (np.abs(_np(rew_g) - rew_o) <= TOL * np.maximum(1.0, np.abs(rew_o))).all(), ctx
+        assert obs_err(_np(obs_g), obs_o) <= TOL, ctx
 
     for t in range(5):
         step_both(f"warm {t}")

@@ -1,0 +1,29 @@
+"""Worst-case reward / observation error of the HIP path vs the oracle over a long seeded batch run."""
+import sys, os
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle
+from golden_util import obs_err, circ_diff, ANGLE_COLS
+from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D
+E, n = 8192, 4
+env = BatchedMultiUAVWorld2D(E, num_agents=n, seed=1)
+orc = oracle.OracleMulti(num_envs=E, num_agents=n, nthreads=16)
+env.reset(); orc.reset_philox(1)
+rng = np.random.default_rng(0)
+wr, wo = 0.0, np.zeros(10)
+for t in range(600):
+    if t % 2:
+        act = rng.uniform(-10, 10, size=(E, n, 2)).astype(np.float32)
+    else:
+        d = orc.tgt - orc.loc; dist = np.linalg.norm(d, axis=-1, keepdims=True)
+        act = d / np.maximum(dist, 1e-9) * np.where(dist > 0.3, np.minimum(8.0, np.sqrt(4.0 * dist)), 0.0)
+    og, rg, dg, _ = env.step(act)
+    oo, ro, do = orc.step(act)
+    assert np.array_equal(dg.cpu().numpy().astype(np.uint8), do)
+    wr = max(wr, float(np.abs(rg.cpu().numpy() - ro).max()))
+    err = np.abs(og.cpu().numpy().astype(np.float64) - oo)
+    for c in ANGLE_COLS: err[..., c] = circ_diff(og.cpu().numpy()[..., c], oo[..., c])
+    wo = np.maximum(wo, err.reshape(-1, 10).max(axis=0))
+print("max reward err %.3g" % wr, " max obs err per column:", np.array2string(wo, precision=2))
+print("reached", int(orc.counters[:, 1].sum()), "collisions", int(orc.counters[:, 2].sum()))
