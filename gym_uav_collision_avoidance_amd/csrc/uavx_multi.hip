@@ -67,7 +67,11 @@ struct MultiParams {
     float *prev_ovr;
     double2 *vel;
     Goal *goal;
-    uint32_t *steps, *reach, *coll, *episode;
+    // env.steps (MUW:238) = wave_steps[wave of the env] - steps_base[env]: a step launch bumps ONE counter per
+    // wavefront (every env of a wave is stepped by the same launches) instead of one word per env; reset and
+    // set_state move the env's base (A/B at 65536x4: per-env counter updates cost 3 % of the launch).
+    uint32_t *wave_steps, *steps_base;
+    uint32_t *reach, *coll, *episode;
     // episode bookkeeping (uavx_step_ex / uavx_reset)
     uint8_t *pending;   // [E] env ended its episode: re-initialise it at the next step_ex call
     float2 *ep_run;     // [E] running {agent-0 return, sum_i r_i*(1-done_i)} of the current episode
@@ -89,6 +93,7 @@ struct LaneMap {
     bool active;
     uint32_t e, a;   // env, agent slot (E*N < 2^26, checked by uavx_create)
     uint32_t a0;     // first agent slot of this wave
+    uint32_t wave;   // global wavefront index (= index into wave_steps)
     int cnt;         // active agent slots in this wave: lanes [0, cnt), slots [a0, a0 + cnt)
 };
 
@@ -108,6 +113,7 @@ __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
         g = (m.lane * p.magic) >> 16;  // floor(lane / N) for lane < 64
         m.i = m.lane - g * N;
     }
+    m.wave = wave;
     const uint32_t E = (uint32_t)p.E;
     const uint32_t e0 = wave * epw;
     const uint32_t envs_here = e0 < E ? min(E - e0, (uint32_t)epw) : 0u;
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
-        if (m.i == 0) atomicAdd(&p.steps[m.e], 1u);          // MUW:238 (no-return atomic: nothing waits on it)
+        if (m.lane == 0) atomicAdd(&p.wave_steps[m.wave], 1u);  // MUW:238 for every env of this wave (no-return)
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
 #endif
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
-    uint32_t steps_v = 0, episode = 0;
+    uint32_t steps_v = 0, episode = 0, wave_count = 0;
     bool do_reset = false;
     float2 run = make_float2(0.f, 0.f);
     // The per-env words are loaded FIRST and the 52 B of agent state after them: vmcnt retires in issue
@@ -571,7 +577,8 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
     // underneath the state loads of the launch-wide read burst instead of extending the wave's tail.
     if (m.active) {
         do_reset = p.pending[m.e] != 0;
-        steps_v = p.steps[m.e];
+        wave_count = p.wave_steps[m.wave];
+        steps_v = wave_count - p.steps_base[m.e];
         episode = p.episode[m.e];
         if (x.track_returns && m.i == 0) run = p.ep_run[m.e];
     }
@@ -631,7 +638,8 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
                          (x.reset_policy == UAVX_RESET_ALL_DONE && all_done) ||
                          (x.step_cap != 0 && steps_next >= x.step_cap);
             ended = ended && !do_reset;
-            p.steps[m.e] = steps_next;
+            if (do_reset) p.steps_base[m.e] = wave_count + 1u;   // steps == 0 after this launch (MUW:166)
+            if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave
             p.pending[m.e] = ended ? 1 : 0;
             if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
             if (do_reset) {  // fold the ended episode; pending/ep_run written below supersede fold_store's
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
         store_agent(p, m.a, s, flags_in);
         if (reach_acc) atomicAdd(&p.reach[m.e], reach_acc);  // MUW:221
         if (coll_acc) atomicAdd(&p.coll[m.e], coll_acc);     // MUW:209
-        if (m.i == 0) atomicAdd(&p.steps[m.e], (uint32_t)K); // MUW:238
+        if (m.lane == 0) atomicAdd(&p.wave_steps[m.wave], (uint32_t)K);  // MUW:238
     }
 }
 
@@ -739,8 +747,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
         p.vel[m.a] = make_double2(0.0, 0.0);
         p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, 0u};
         if (m.i == 0) {
-            fold_store(p, m.e, p.steps[m.e], episode, fold_load(p, m.e));
-            p.steps[m.e] = 0;  // MUW:166
+            const uint32_t wc = p.wave_steps[m.wave];
+            fold_store(p, m.e, wc - p.steps_base[m.e], episode, fold_load(p, m.e));
+            p.steps_base[m.e] = wc;  // MUW:166 steps = 0
         }
     }
 }
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_s
         if (v.init_d) v.init_d[a] = g.init_d;
     }
     if (a < p.E && v.counters) {
-        v.counters[4 * a + 0] = p.steps[a]; v.counters[4 * a + 1] = p.reach[a];
+        v.counters[4 * a + 0] = p.wave_steps[a / p.epw] - p.steps_base[a]; v.counters[4 * a + 1] = p.reach[a];
         v.counters[4 * a + 2] = p.coll[a];  v.counters[4 * a + 3] = p.episode[a];
     }
 }
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_s
         if (v.vel) p.vel[a] = make_double2(v.vel[2 * a], v.vel[2 * a + 1]);
     }
     if (a < p.E && v.counters) {
-        p.steps[a] = v.counters[4 * a + 0]; p.reach[a] = v.counters[4 * a + 1];
+        p.steps_base[a] = p.wave_steps[a / p.epw] - v.counters[4 * a + 0]; p.reach[a] = v.counters[4 * a + 1];
         p.coll[a] = v.counters[4 * a + 2];  p.episode[a] = v.counters[4 * a + 3];
     }
 }
@@ -1004,6 +1013,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_vel = off;  off = align_up(off + A * sizeof(double2), 256);
     const size_t o_goal = off; off = align_up(off + A * sizeof(Goal), 256);
     const size_t o_steps = off; off = align_up(off + E * 4, 256);
+    const size_t o_wsteps = off; off = align_up(off + ((E + (kWave / N) - 1) / (kWave / N)) * 4, 256);
     const size_t o_reach = off; off = align_up(off + E * 4, 256);
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
     const size_t o_epi = off;   off = align_up(off + E * 4, 256);
@@ -1020,7 +1030,8 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.prev_ovr = reinterpret_cast<float *>(b + o_ovr);
     p.vel = reinterpret_cast<double2 *>(b + o_vel);
     p.goal = reinterpret_cast<Goal *>(b + o_goal);
-    p.steps = reinterpret_cast<uint32_t *>(b + o_steps);
+    p.steps_base = reinterpret_cast<uint32_t *>(b + o_steps);
+    p.wave_steps = reinterpret_cast<uint32_t *>(b + o_wsteps);
     p.reach = reinterpret_cast<uint32_t *>(b + o_reach);
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
     p.episode = reinterpret_cast<uint32_t *>(b + o_epi);
