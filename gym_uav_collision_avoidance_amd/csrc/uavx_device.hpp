@@ -78,22 +78,28 @@ __device__ __forceinline__ float wrap_pi(float x) {
 // Markstein form q0 = RN(x*r), rem = fma(-q0, tau, x) (exact), q = fma(rem, r, q0) returns the IEEE
 // quotient (checked against x/tau on 2.1e9 samples for tau = 0.02 and six other steps; uavx_create
 // re-checks the handle's tau on 1e5 samples and falls back to '/' if a single one differs).
-// |x| is capped at 1e300 first so an infinite action still ends at the clip limit like np.clip does.
+// |x| is capped at 1e300 first so an infinite action still ends at the clip limit like np.clip does
+// (a NaN turns into a finite value here; axis_update() poisons the result afterwards).
 __device__ __forceinline__ double div_tau(double x, double tau, double rtau, bool recip_ok) {
     if (!recip_ok) return x / tau;
-    x = (x > 1e300) ? 1e300 : x;
-    x = (x < -1e300) ? -1e300 : x;
+    x = fmin(fmax(x, -1e300), 1e300);
     const double q0 = x * rtau;
     const double rem = fma(-q0, tau, x);
     return fma(rem, rtau, q0);
 }
 
-// One double-integrator axis update, AG:26-29, float64 with a float32 position accumulate.
+// One double-integrator axis update, AG:26-29, float64 with a float32 position accumulate.  np.clip is
+// done with v_max_f64 / v_min_f64 (one instruction each instead of compare + two selects); those return the
+// non-NaN operand, so a NaN action or velocity is detected once (unordered compare) and put back, which
+// is what np.clip / the reference would propagate.
 __device__ __forceinline__ void axis_update(double a, double tau, double rtau, bool recip_ok, double amax, double vmax,
                                             double &v, float &x) {
-    double dv = clip64(div_tau(a - v, tau, rtau, recip_ok), -amax, amax);  // AG:26
-    v = clip64(v + dv * tau, -vmax, vmax);                                 // AG:27
-    x = (float)((double)x + v * tau);                                      // AG:28-29 (float32 array += float64 array)
+    const bool poisoned = __builtin_isunordered(a, v);
+    const double dv = fmin(fmax(div_tau(a - v, tau, rtau, recip_ok), -amax), amax);  // AG:26
+    double nv = fmin(fmax(v + dv * tau, -vmax), vmax);                               // AG:27
+    nv = poisoned ? __builtin_nan("") : nv;
+    v = nv;
+    x = (float)((double)x + v * tau);                                                // AG:28-29 (float32 array += float64 array)
 }
 
 // Philox4x32-10, counter-based: one call yields the two 53-bit uniforms of one

@@ -423,3 +423,32 @@ def test_poked_state_keeps_reference_prev_distance_semantics(amd, oracle_mod):
         assert torch.equal(st[k], st2[k]), k
     step_both("after round trip")
     env.close()
+
+
+def test_nonfinite_actions_propagate_like_numpy(amd, oracle_mod):
+    """np.clip lets NaN through and clips +-inf (AG:26-27): a NaN command poisons that agent's velocity and
+    position for good, an infinite one just saturates the acceleration.  The device path must do the same."""
+    E, n = 64, 4
+    env = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=2)
+    orc = oracle_mod.OracleMulti(num_envs=E, num_agents=n)
+    env.reset(); orc.reset_philox(2)
+    rng = np.random.default_rng(1)
+    for t in range(6):
+        act = rng.uniform(-10, 10, size=(E, n, 2))
+        if t == 1:
+            act[0, 1, 0] = np.inf; act[1, 2, 1] = -np.inf; act[2, 0, :] = [np.inf, -np.inf]
+        if t == 2:
+            act[3, 3, 0] = np.nan; act[4, 0, 1] = np.nan
+        obs_g, rew_g, done_g, _ = env.step(act)
+        obs_o, rew_o, done_o = orc.step(act)
+        st = env.get_state()
+        np.testing.assert_array_equal(_np(st["vel"]), orc.vel, err_msg=f"step {t}")          # NaN == NaN here
+        np.testing.assert_array_equal(_np(st["loc"]), orc.loc.astype(np.float32), err_msg=f"step {t}")
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=f"step {t}")
+        np.testing.assert_array_equal(_np(st["flags"]), orc.flags, err_msg=f"step {t}")
+        finite = np.isfinite(obs_o).all(axis=-1) & np.isfinite(rew_o)
+        assert obs_err(_np(obs_g)[finite], obs_o[finite]) <= TOL
+        assert float(np.abs(_np(rew_g)[finite] - rew_o[finite]).max()) <= TOL
+        assert np.isnan(_np(obs_g)[~finite]).any(axis=-1).all() if (~finite).any() else True
+    assert np.isnan(orc.vel[3, 3]).any() and np.isnan(orc.vel[4, 0]).any() and np.isfinite(orc.vel[0, 1]).all()
+    env.close()
