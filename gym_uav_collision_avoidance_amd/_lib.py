@@ -21,6 +21,7 @@ SYMBOLS = (
     "uavx_set_state", "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
     "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
     "uavx_uw_reset", "uavx_uw_step", "uavx_uw_observe", "uavx_uw_get_state", "uavx_uw_set_state",
+    "uavx_uw_step_ex", "uavx_uw_get_episode_stats", "uavx_uw_clear_episode_stats",
 )
 
 
@@ -51,6 +52,14 @@ class StepArgs(ctypes.Structure):  # uavx_step_args
                 ("evaluate", ctypes.c_int32), ("reset_policy", ctypes.c_int32), ("step_cap", ctypes.c_uint32),
                 ("track_returns", ctypes.c_int32), ("seed", ctypes.c_uint64), ("obs", ctypes.c_void_p),
                 ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p)]
+
+class UWStepArgs(ctypes.Structure):  # uavx_uw_step_args
+    _fields_ = [("actions", ctypes.c_void_p), ("action_dtype", ctypes.c_int32), ("action_mode", ctypes.c_int32),
+                ("auto_reset", ctypes.c_int32), ("step_cap", ctypes.c_uint32), ("track_returns", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("seed", ctypes.c_uint64), ("obs", ctypes.c_void_p),
+                ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("info_distance", ctypes.c_void_p),
+                ("reset_mask", ctypes.c_void_p)]
+
 
 _lib = None
 
@@ -103,6 +112,9 @@ def load():
     L.uavx_uw_observe.argtypes = [vp, vp, vp]
     L.uavx_uw_get_state.argtypes = [vp, ctypes.POINTER(UWStateView), vp]
     L.uavx_uw_set_state.argtypes = [vp, ctypes.POINTER(UWStateView), vp]
+    L.uavx_uw_step_ex.argtypes = [vp, ctypes.POINTER(UWStepArgs), vp]
+    L.uavx_uw_get_episode_stats.argtypes = [vp, vp, vp, vp]
+    L.uavx_uw_clear_episode_stats.argtypes = [vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("uavx_version",):

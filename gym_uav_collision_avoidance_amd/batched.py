@@ -402,6 +402,32 @@ class BatchedUAVWorld2D(_Base):
                                         self._done.data_ptr(), self._info.data_ptr(), self._stream()), self._h, uw=True)
         return obs, self._rew, self._done.view(torch.bool), {"distance": self._info}
 
+    def step_ex(self, actions, polar=False, auto_reset=False, step_cap=0, track_returns=True):
+        """env.step plus the single-agent trainer loop's bookkeeping (test_sac.py:77-80,98,106-109): polar=True
+        converts policy outputs a in [-1,1]^2 (v = (a0/2+0.5)*action_space.high[0], theta = a1*pi); auto_reset
+        re-initialises an env in the call AFTER the one that returned done (info["reset_mask"]); episode returns
+        and lengths are accumulated per env (episode_stats())."""
+        a, code = self._actions_arg(actions, (self.num_envs, 2))
+        obs = self._next_obs_buf()
+        if not hasattr(self, "_reset_mask"):
+            self._reset_mask = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+        args = _lib.UWStepArgs(a.data_ptr(), code, _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN,
+                               int(bool(auto_reset)), int(step_cap), int(bool(track_returns)), 0, self.seed,
+                               obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(), self._info.data_ptr(),
+                               self._reset_mask.data_ptr())
+        _lib.check(self._L.uavx_uw_step_ex(self._h, ctypes.byref(args), self._stream()), self._h, uw=True)
+        return obs, self._rew, self._done.view(torch.bool), {"distance": self._info,
+                                                             "reset_mask": self._reset_mask.view(torch.bool)}
+
+    def episode_stats(self):
+        c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)
+        r = torch.empty((self.num_envs,), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.uavx_uw_get_episode_stats(self._h, c.data_ptr(), r.data_ptr(), self._stream()), self._h, uw=True)
+        return dict(episodes=c[:, 0], steps=c[:, 1], reached=c[:, 2], returns=r)
+
+    def clear_episode_stats(self):
+        _lib.check(self._L.uavx_uw_clear_episode_stats(self._h, self._stream()), self._h, uw=True)
+
     def observe(self):
         obs = self._next_obs_buf()
         _lib.check(self._L.uavx_uw_observe(self._h, obs.data_ptr(), self._stream()), self._h, uw=True)

@@ -102,6 +102,27 @@ __device__ __forceinline__ void axis_update(double a, double tau, double rtau, b
     x = (float)((double)x + v * tau);                                                // AG:28-29 (float32 array += float64 array)
 }
 
+// sin(pi*t), cos(pi*t) in float32: quarter-turn reduction + Taylor polynomials on |r| <= 1/4
+// (|error| < 1e-7).  Fixed fmaf sequence so the CPU oracle can restate it bit for bit.
+__device__ __forceinline__ void sincospi32(float t, float &sn, float &cs) {
+    const float k = rintf(2.0f * t);
+    const float r = fmaf(-0.5f, k, t);
+    const float z = r * r;
+    float ps = fmaf(z, 0.0821458866f, -0.599264529f);    //  pi^9/9!, -pi^7/7!
+    ps = fmaf(ps, z, 2.55016404f);                       //  pi^5/5!
+    ps = fmaf(ps, z, -5.16771278f);                      // -pi^3/3!
+    ps = fmaf(ps, z, 3.14159265f);
+    ps = ps * r;
+    float pc = fmaf(z, -0.0258068913f, 0.235330630f);    // -pi^10/10!, pi^8/8!
+    pc = fmaf(pc, z, -1.33526277f);                      // -pi^6/6!
+    pc = fmaf(pc, z, 4.05871213f);                       //  pi^4/4!
+    pc = fmaf(pc, z, -4.93480220f);                      // -pi^2/2!
+    pc = fmaf(pc, z, 1.0f);
+    const int q = (int)k & 3;
+    sn = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    cs = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+
 // Philox4x32-10, counter-based: one call yields the two 53-bit uniforms of one
 // np.random.uniform(lo, hi, (2,)) draw (MUW:126,131,144; UW:121-126).
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

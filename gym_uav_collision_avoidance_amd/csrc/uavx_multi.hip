@@ -515,27 +515,6 @@ __device__ __forceinline__ void fold_store(const MultiParams &p, uint32_t e, uin
     p.pending[e] = 0;
 }
 
-// sin(pi*t), cos(pi*t) in float32: quarter-turn reduction + Taylor polynomials on |r| <= 1/4
-// (|error| < 1e-7).  Fixed fmaf sequence so the CPU oracle can restate it bit for bit.
-__device__ __forceinline__ void sincospi32(float t, float &sn, float &cs) {
-    const float k = rintf(2.0f * t);
-    const float r = fmaf(-0.5f, k, t);
-    const float z = r * r;
-    float ps = fmaf(z, 0.0821458866f, -0.599264529f);    //  pi^9/9!, -pi^7/7!
-    ps = fmaf(ps, z, 2.55016404f);                       //  pi^5/5!
-    ps = fmaf(ps, z, -5.16771278f);                      // -pi^3/3!
-    ps = fmaf(ps, z, 3.14159265f);
-    ps = ps * r;
-    float pc = fmaf(z, -0.0258068913f, 0.235330630f);    // -pi^10/10!, pi^8/8!
-    pc = fmaf(pc, z, -1.33526277f);                      // -pi^6/6!
-    pc = fmaf(pc, z, 4.05871213f);                       //  pi^4/4!
-    pc = fmaf(pc, z, -4.93480220f);                      // -pi^2/2!
-    pc = fmaf(pc, z, 1.0f);
-    const int q = (int)k & 3;
-    sn = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
-    cs = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
-}
-
 // test_sac_multi.py:77-80 in float32: a in [-1,1]^2 -> velocity command.
 __device__ __forceinline__ void polar_to_command(const MultiParams &p, float a0, float a1, double &ax, double &ay) {
     const float v = fmaf(a0, 0.5f, 0.5f) * p.vmax_norm;

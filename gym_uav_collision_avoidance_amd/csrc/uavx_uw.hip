@@ -20,6 +20,7 @@ struct UwParams {
     double tau, amax, vmax;
     double lox, loy, hix, hiy;
     float tau_f;       // float32(tau): UW:142 divides a float32 array by the python float
+    float high0;       // float32(action_space.high[0]) = max_speed (test_sac.py:77)
     float inv_vmax;    // 1/max_speed[0]            UW:88
     float inv_diag;    // 1/‖(x_size,y_size)‖       UW:17,97
     int64_t E, env_offset;
@@ -27,11 +28,87 @@ struct UwParams {
     double2 *vel;
     float *goal;
     uint32_t *steps, *episode;
+    // episode bookkeeping (uavx_uw_step_ex / uavx_uw_reset)
+    uint8_t *pending;     // [E] episode ended: re-initialise at the next step_ex call
+    float *ep_return;     // [E] running return of the current episode
+    uint4 *fin_counts;    // [E] {episodes, steps, episodes ended at the target, last-step-was-success scratch}
+    float *fin_return;    // [E] sum of ended episodes' returns
+};
+
+struct UwExtra {
+    int action_mode, auto_reset, track_returns;
+    uint32_t step_cap, seed_lo, seed_hi;
+    uint8_t *reset_mask;
 };
 
 // UW:88-97 in float32
 __device__ __forceinline__ float4 uw_obs(const UwParams &p, float speed, float theta, float dist_t, float dth) {
     return make_float4(speed * p.inv_vmax, theta * kInvPi, dist_t * p.inv_diag, dth * kInvPi);
+}
+
+constexpr uint32_t kUwReached = 8u;  // internal flag bit: the last step ended at the target (d < 0.5, UW:159)
+
+struct UwRegs {
+    float x, y, prev_d, tx, ty, init_d;
+    uint32_t flags;
+    double vx, vy;
+};
+
+// UW:137-173 for one env held in registers.  act_f32: the command came as float32 (first-step quirk of UW:142).
+__device__ __forceinline__ void uw_step_env(const UwParams &p, UwRegs &s, double ax, double ay, bool act_f32,
+                                            float4 &obs, float &rew, uint32_t &done, float &dist) {
+    const bool f32_first = act_f32 && (s.flags & UAVX_FLAG_VEL_F32) != 0;  // float32 action - float32 velocity, / float32(tau)
+    double qx, qy;
+    if (f32_first) {
+        qx = (double)(((float)ax - (float)s.vx) / p.tau_f);
+        qy = (double)(((float)ay - (float)s.vy) / p.tau_f);
+    } else {
+        qx = (ax - s.vx) / p.tau;
+        qy = (ay - s.vy) / p.tau;
+    }
+    s.vx = clip64(s.vx + clip64(qx, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);  // UW:142-144
+    s.vy = clip64(s.vy + clip64(qy, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);
+    s.x = (float)((double)s.x + s.vx * p.tau);                                   // UW:145-146
+    s.y = (float)((double)s.y + s.vy * p.tau);
+    const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);  // UW:149,162
+    const float tdx = s.tx - s.x, tdy = s.ty - s.y;
+    const float d = norm32(tdx, tdy);                        // UW:150
+    const float theta = atan2f((float)s.vy, (float)s.vx);    // UW:89
+    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);     // UW:155-156
+    float r = 0.0f - 1.0f / s.init_d;                        // UW:152-153 (float32 under NEP 50)
+    r = r + 10.0f * (s.prev_d - d);                          // UW:154
+    r = r - 0.1f * fabsf(dth);                               // UW:157
+    done = 0;
+    if (d < 0.5f) { done = 1; r = r + 1000.0f; }             // UW:159-161
+    else if (oob) done = 1;                                  // UW:162-163
+    const float speed = sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
+    obs = uw_obs(p, speed, theta, d, dth);                   // UW:168
+    rew = r;
+    dist = d;
+    s.prev_d = d;                                            // UW:172
+    s.flags = (s.flags & ~(UAVX_FLAG_VEL_F32 | kUwReached)) | (d < 0.5f ? kUwReached : 0u);  // UW:147: velocity is float64 now
+}
+
+__device__ __forceinline__ void uw_load(const UwParams &p, int64_t e, UwRegs &s) {
+    const float4 d4 = p.dyn[e];
+    const double2 v = p.vel[e];
+    s.x = d4.x; s.y = d4.y; s.prev_d = d4.z; s.flags = __float_as_uint(d4.w);
+    s.vx = v.x; s.vy = v.y;
+    s.tx = p.goal[3 * e]; s.ty = p.goal[3 * e + 1]; s.init_d = p.goal[3 * e + 2];
+}
+__device__ __forceinline__ void uw_store(const UwParams &p, int64_t e, const UwRegs &s) {
+    p.dyn[e] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags));
+    p.vel[e] = make_double2(s.vx, s.vy);
+}
+template <bool ACT64>
+__device__ __forceinline__ void uw_load_action(const void *__restrict__ actions, int64_t e, double &ax, double &ay) {
+    if (ACT64) {
+        const double2 a = reinterpret_cast<const double2 *>(actions)[e];
+        ax = a.x; ay = a.y;
+    } else {
+        const float2 a = reinterpret_cast<const float2 *>(actions)[e];
+        ax = (double)a.x; ay = (double)a.y;
+    }
 }
 
 template <bool ACT64>
@@ -40,55 +117,108 @@ __global__ __launch_bounds__(kBlock) void uw_step_kernel(UwParams p, const void 
                                                          uint8_t *__restrict__ done_out, float *__restrict__ info_out) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
-    const float4 d4 = p.dyn[e];
-    double2 v = p.vel[e];
-    float x = d4.x, y = d4.y;
-    const float prev_d = d4.z;
-    const uint32_t flags = __float_as_uint(d4.w);
-    const float tx = p.goal[3 * e], ty = p.goal[3 * e + 1], init_d = p.goal[3 * e + 2];
+    UwRegs s;
+    uw_load(p, e, s);
     double ax, ay;
-    bool f32_first = false;
-    if (ACT64) {
-        const double2 a = reinterpret_cast<const double2 *>(actions)[e];
-        ax = a.x; ay = a.y;
-    } else {
-        const float2 a = reinterpret_cast<const float2 *>(actions)[e];
-        ax = (double)a.x; ay = (double)a.y;
-        f32_first = (flags & UAVX_FLAG_VEL_F32) != 0;  // float32 action - float32 velocity, / float32(tau)
-    }
-    {   // UW:142-147
-        double qx, qy;
-        if (f32_first) {
-            qx = (double)(((float)ax - (float)v.x) / p.tau_f);
-            qy = (double)(((float)ay - (float)v.y) / p.tau_f);
-        } else {
-            qx = (ax - v.x) / p.tau;
-            qy = (ay - v.y) / p.tau;
-        }
-        v.x = clip64(v.x + clip64(qx, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);
-        v.y = clip64(v.y + clip64(qy, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);
-        x = (float)((double)x + v.x * p.tau);
-        y = (float)((double)y + v.y * p.tau);
-    }
-    const bool oob = !((double)x >= p.lox && (double)x <= p.hix && (double)y >= p.loy && (double)y <= p.hiy);  // UW:149,162
-    const float tdx = tx - x, tdy = ty - y;
-    const float d = norm32(tdx, tdy);                        // UW:150
-    const float theta = atan2f((float)v.y, (float)v.x);      // UW:89
-    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);     // UW:155-156
-    float r = 0.0f - 1.0f / init_d;                          // UW:152-153 (float32 under NEP 50)
-    r = r + 10.0f * (prev_d - d);                            // UW:154
-    r = r - 0.1f * fabsf(dth);                               // UW:157
-    uint32_t dn = 0;
-    if (d < 0.5f) { dn = 1; r = r + 1000.0f; }               // UW:159-161
-    else if (oob) dn = 1;                                    // UW:162-163
-    const float speed = sqrtf((float)fma(v.y, v.y, v.x * v.x));
-    obs_out[e] = uw_obs(p, speed, theta, d, dth);            // UW:168
-    rew_out[e] = r;
+    uw_load_action<ACT64>(actions, e, ax, ay);
+    float4 obs; float rew, dist; uint32_t dn;
+    uw_step_env(p, s, ax, ay, !ACT64, obs, rew, dn, dist);
+    obs_out[e] = obs;
+    rew_out[e] = rew;
     done_out[e] = (uint8_t)dn;
-    if (info_out) info_out[e] = d;                           // UW:114-117
-    p.dyn[e] = make_float4(x, y, d, __uint_as_float(flags & ~UAVX_FLAG_VEL_F32));  // UW:172
-    p.vel[e] = v;
+    if (info_out) info_out[e] = dist;                        // UW:114-117
+    uw_store(p, e, s);
     p.steps[e] += 1;                                         // UW:170
+}
+
+// UW:119-131 for one env into registers; stream = the one uw_reset_kernel uses (counter: env, draw, episode).
+__device__ __forceinline__ void uw_draw_episode(const UwParams &p, int64_t e, uint32_t episode, uint32_t k0, uint32_t k1,
+                                                UwRegs &s) {
+    const uint64_t ge = (uint64_t)(p.env_offset + e);
+    PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), episode, k0, k1, 0u};
+    float vx, vy;
+    rng.point32(p.lox, p.loy, p.hix, p.hiy, s.x, s.y);                   // UW:121
+    rng.point32(-p.vmax, -p.vmax, p.vmax, p.vmax, vx, vy);               // UW:122
+    rng.point32(p.lox, p.loy, p.hix, p.hiy, s.tx, s.ty);                 // UW:126
+    s.vx = (double)vx; s.vy = (double)vy;
+    s.init_d = s.prev_d = norm32(s.tx - s.x, s.ty - s.y);                // UW:129-130
+    s.flags = UAVX_FLAG_VEL_F32;
+}
+
+// An episode of env e ends: fold it into the statistics (test_sac.py:98,106-109).
+__device__ __forceinline__ void uw_fold(const UwParams &p, int64_t e, uint32_t steps, bool reached) {
+    if (steps != 0) {
+        uint4 c = p.fin_counts[e];
+        c.x += 1; c.y += steps; c.z += reached ? 1u : 0u;
+        p.fin_counts[e] = c;
+        p.fin_return[e] += p.ep_return[e];
+    }
+    p.ep_return[e] = 0.f;
+    p.pending[e] = 0;
+}
+
+// uavx_uw_step_ex: step + polar conversion + next-step auto-reset + episode statistics.
+template <bool ACT64>
+__global__ __launch_bounds__(kBlock) void uw_step_ex_kernel(UwParams p, UwExtra x, const void *__restrict__ actions,
+                                                            float4 *__restrict__ obs_out, float *__restrict__ rew_out,
+                                                            uint8_t *__restrict__ done_out, float *__restrict__ info_out) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.E) return;
+    const uint32_t pend = p.pending[e];
+    uint32_t steps = p.steps[e];
+    UwRegs s;
+    if (pend) {  // the env starts a new episode instead of stepping
+        const uint32_t episode = p.episode[e];
+        uw_fold(p, e, steps, (__float_as_uint(p.dyn[e].w) & kUwReached) != 0);
+        uw_draw_episode(p, e, episode, x.seed_lo, x.seed_hi, s);
+        p.episode[e] = episode + 1;
+        p.goal[3 * e] = s.tx; p.goal[3 * e + 1] = s.ty; p.goal[3 * e + 2] = s.init_d;
+        uw_store(p, e, s);
+        p.steps[e] = 0;                                                  // UW:131
+        const float tdx = s.tx - s.x, tdy = s.ty - s.y;
+        const float theta = atan2f((float)s.vy, (float)s.vx);
+        obs_out[e] = uw_obs(p, norm32((float)s.vx, (float)s.vy), theta, s.init_d, wrap_pi(atan2f(tdy, tdx) - theta));
+        rew_out[e] = 0.f;
+        done_out[e] = 0;
+        if (info_out) info_out[e] = s.init_d;
+        if (x.reset_mask) x.reset_mask[e] = 1;
+        return;
+    }
+    uw_load(p, e, s);
+    double ax, ay;
+    uw_load_action<ACT64>(actions, e, ax, ay);
+    bool act_f32 = !ACT64;
+    if (x.action_mode == UAVX_ACTION_POLAR) {  // test_sac.py:77-80 in float32
+        const float v = fmaf((float)ax, 0.5f, 0.5f) * p.high0;
+        float sn, cs;
+        sincospi32((float)ay, sn, cs);
+        ax = (double)(v * cs); ay = (double)(v * sn);
+        act_f32 = true;
+    }
+    float4 obs; float rew, dist; uint32_t dn;
+    uw_step_env(p, s, ax, ay, act_f32, obs, rew, dn, dist);
+    obs_out[e] = obs;
+    rew_out[e] = rew;
+    done_out[e] = (uint8_t)dn;
+    if (info_out) info_out[e] = dist;
+    uw_store(p, e, s);
+    steps += 1;
+    p.steps[e] = steps;                                                  // UW:170
+    const bool ended = (x.auto_reset && dn) || (x.step_cap != 0 && steps >= x.step_cap);
+    p.pending[e] = ended ? (uint8_t)1 : (uint8_t)0;
+    if (x.track_returns) p.ep_return[e] += rew;                          // test_sac.py:98
+    if (x.reset_mask) x.reset_mask[e] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void uw_episode_stats_kernel(UwParams p, uint32_t *counts, float *returns, int clear) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.E) return;
+    if (clear) { p.fin_counts[e] = make_uint4(0, 0, 0, 0); p.fin_return[e] = 0.f; return; }
+    if (counts) {
+        const uint4 c = p.fin_counts[e];
+        counts[4 * e] = c.x; counts[4 * e + 1] = c.y; counts[4 * e + 2] = c.z; counts[4 * e + 3] = 0;
+    }
+    if (returns) returns[e] = p.fin_return[e];
 }
 
 __global__ __launch_bounds__(kBlock) void uw_observe_kernel(UwParams p, float4 *__restrict__ obs_out) {
@@ -108,18 +238,14 @@ __global__ __launch_bounds__(kBlock) void uw_reset_kernel(UwParams p, const uint
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
     if (mask && !mask[e]) return;
-    const uint64_t ge = (uint64_t)(p.env_offset + e);
-    PhiloxDraws rng{(uint32_t)ge, (uint32_t)(ge >> 32), p.episode[e], (uint32_t)seed, (uint32_t)(seed >> 32), 0u};
-    float x, y, vx, vy, tx, ty;
-    rng.point32(p.lox, p.loy, p.hix, p.hiy, x, y);                       // UW:121
-    rng.point32(-p.vmax, -p.vmax, p.vmax, p.vmax, vx, vy);               // UW:122
-    rng.point32(p.lox, p.loy, p.hix, p.hiy, tx, ty);                     // UW:126
-    const float d0 = norm32(tx - x, ty - y);                             // UW:129
-    p.dyn[e] = make_float4(x, y, d0, __uint_as_float(UAVX_FLAG_VEL_F32)); // UW:130
-    p.vel[e] = make_double2((double)vx, (double)vy);
-    p.goal[3 * e] = tx; p.goal[3 * e + 1] = ty; p.goal[3 * e + 2] = d0;
+    const uint32_t episode = p.episode[e];
+    UwRegs s;
+    uw_draw_episode(p, e, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
+    uw_fold(p, e, p.steps[e], (__float_as_uint(p.dyn[e].w) & kUwReached) != 0);
+    uw_store(p, e, s);
+    p.goal[3 * e] = s.tx; p.goal[3 * e + 1] = s.ty; p.goal[3 * e + 2] = s.init_d;
     p.steps[e] = 0;                                                      // UW:131
-    p.episode[e] += 1;
+    p.episode[e] = episode + 1;
 }
 
 __global__ __launch_bounds__(kBlock) void uw_get_state_kernel(UwParams p, uavx_uw_state_view v) {
@@ -128,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void uw_get_state_kernel(UwParams p, uavx_u
     const float4 d = p.dyn[e];
     if (v.loc) { v.loc[2 * e] = d.x; v.loc[2 * e + 1] = d.y; }
     if (v.prev_d) v.prev_d[e] = d.z;
-    if (v.flags) v.flags[e] = (uint8_t)__float_as_uint(d.w);
+    if (v.flags) v.flags[e] = (uint8_t)(__float_as_uint(d.w) & UAVX_FLAG_VEL_F32);
     if (v.vel) { const double2 w = p.vel[e]; v.vel[2 * e] = w.x; v.vel[2 * e + 1] = w.y; }
     if (v.tgt) { v.tgt[2 * e] = p.goal[3 * e]; v.tgt[2 * e + 1] = p.goal[3 * e + 1]; }
     if (v.init_d) v.init_d[e] = p.goal[3 * e + 2];
@@ -141,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void uw_set_state_kernel(UwParams p, uavx_u
     float4 d = p.dyn[e];
     if (v.loc) { d.x = v.loc[2 * e]; d.y = v.loc[2 * e + 1]; }
     if (v.prev_d) d.z = v.prev_d[e];
-    if (v.flags) d.w = __uint_as_float((uint32_t)v.flags[e]);
+    if (v.flags) d.w = __uint_as_float((uint32_t)v.flags[e] & UAVX_FLAG_VEL_F32);
     p.dyn[e] = d;
     if (v.vel) p.vel[e] = make_double2(v.vel[2 * e], v.vel[2 * e + 1]);
     if (v.tgt) { p.goal[3 * e] = v.tgt[2 * e]; p.goal[3 * e + 1] = v.tgt[2 * e + 1]; }
@@ -212,6 +338,7 @@ int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offs
     p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0; p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;
     p.tau_f = (float)cfg->tau;
+    p.high0 = (float)cfg->max_speed;
     p.inv_vmax = (float)(1.0 / cfg->max_speed);
     p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
     p.E = num_envs;
@@ -225,6 +352,10 @@ int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offs
     const size_t o_goal = off; off = uw_align(off + E * 3 * sizeof(float));
     const size_t o_steps = off; off = uw_align(off + E * 4);
     const size_t o_epi = off;   off = uw_align(off + E * 4);
+    const size_t o_pend = off;  off = uw_align(off + E);
+    const size_t o_ret = off;   off = uw_align(off + E * 4);
+    const size_t o_finc = off;  off = uw_align(off + E * sizeof(uint4));
+    const size_t o_finr = off;  off = uw_align(off + E * 4);
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     if (hipMemset(h->slab, 0, off) != hipSuccess) { (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP; }
     char *b = static_cast<char *>(h->slab);
@@ -233,6 +364,10 @@ int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offs
     p.goal = reinterpret_cast<float *>(b + o_goal);
     p.steps = reinterpret_cast<uint32_t *>(b + o_steps);
     p.episode = reinterpret_cast<uint32_t *>(b + o_epi);
+    p.pending = reinterpret_cast<uint8_t *>(b + o_pend);
+    p.ep_return = reinterpret_cast<float *>(b + o_ret);
+    p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
+    p.fin_return = reinterpret_cast<float *>(b + o_finr);
     *out = h;
     return UAVX_OK;
 }
@@ -286,6 +421,47 @@ int uavx_uw_step(uavx_uw_handle *h, const void *actions, int action_dtype, float
     else
         hipLaunchKernelGGL((uw_step_kernel<false>), env_grid(h), dim3(kBlock), 0, st, h->p, actions,
                            reinterpret_cast<float4 *>(obs), rew, done, info_distance);
+    UW_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_uw_step_ex(uavx_uw_handle *h, const uavx_uw_step_args *a, void *stream) {
+    if (!h || !a) return UAVX_ERR_INVALID_ARG;
+    if (!a->actions || !a->obs || !a->rew || !a->done) return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step_ex: NULL buffer");
+    if (a->action_dtype != UAVX_F32 && a->action_dtype != UAVX_F64)
+        return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step_ex: action_dtype must be UAVX_F32 or UAVX_F64");
+    if (a->action_mode != UAVX_ACTION_CARTESIAN && a->action_mode != UAVX_ACTION_POLAR)
+        return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step_ex: unknown action_mode");
+    UW_ENTER(h);
+    UwExtra x;
+    x.action_mode = a->action_mode; x.auto_reset = a->auto_reset; x.track_returns = a->track_returns;
+    x.step_cap = a->step_cap; x.seed_lo = (uint32_t)a->seed; x.seed_hi = (uint32_t)(a->seed >> 32);
+    x.reset_mask = a->reset_mask;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a->action_dtype == UAVX_F64)
+        hipLaunchKernelGGL((uw_step_ex_kernel<true>), env_grid(h), dim3(kBlock), 0, st, h->p, x, a->actions,
+                           reinterpret_cast<float4 *>(a->obs), a->rew, a->done, a->info_distance);
+    else
+        hipLaunchKernelGGL((uw_step_ex_kernel<false>), env_grid(h), dim3(kBlock), 0, st, h->p, x, a->actions,
+                           reinterpret_cast<float4 *>(a->obs), a->rew, a->done, a->info_distance);
+    UW_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_uw_get_episode_stats(uavx_uw_handle *h, uint32_t *counts, float *returns, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    UW_ENTER(h);
+    hipLaunchKernelGGL(uw_episode_stats_kernel, env_grid(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->p,
+                       counts, returns, 0);
+    UW_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_uw_clear_episode_stats(uavx_uw_handle *h, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    UW_ENTER(h);
+    hipLaunchKernelGGL(uw_episode_stats_kernel, env_grid(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->p,
+                       (uint32_t *)nullptr, (float *)nullptr, 1);
     UW_HIP(h, hipGetLastError());
     return UAVX_OK;
 }

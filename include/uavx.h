@@ -196,6 +196,31 @@ int uavx_uw_reset(uavx_uw_handle *h, const uint8_t *mask, uint64_t seed, float *
 int uavx_uw_step(uavx_uw_handle *h, const void *actions, int action_dtype, float *obs, float *rew,
                  uint8_t *done, float *info_distance, void *stream);
 int uavx_uw_observe(uavx_uw_handle *h, float *obs, void *stream);               /* UW:77-112 */
+
+/* UAVWorld2D counterpart of uavx_step_ex: what test_sac.py:62-109 does around env.step — action
+ * conversion v = (a0/2+0.5)*action_space.high[0], theta = a1*pi (:77-80, float32 on the device), score
+ * accumulation (:98) and reset when done (:106-109) or at a step cap (:17).  Same next-step auto-reset
+ * contract as uavx_step_ex (terminal observation stays in the ending call's outputs). */
+typedef struct {
+    const void *actions;   /* [E*2] */
+    int32_t action_dtype;  /* uavx_dtype */
+    int32_t action_mode;   /* uavx_action_mode */
+    int32_t auto_reset;    /* 0: the caller resets; 1: reset an env after a step that returned done */
+    uint32_t step_cap;     /* 0 = none */
+    int32_t track_returns;
+    int32_t reserved;
+    uint64_t seed;
+    float *obs;            /* [E*4] */
+    float *rew;            /* [E] */
+    uint8_t *done;         /* [E] */
+    float *info_distance;  /* [E] or NULL */
+    uint8_t *reset_mask;   /* [E] or NULL */
+} uavx_uw_step_args;
+int uavx_uw_step_ex(uavx_uw_handle *h, const uavx_uw_step_args *args, void *stream);
+/* counts [E*4] uint32 = episodes, sum of steps, episodes that ended at the target (UW:159), reserved;
+ * returns [E] float32 = sum of episode returns (test_sac.py:98 `score`).  Either may be NULL. */
+int uavx_uw_get_episode_stats(uavx_uw_handle *h, uint32_t *counts, float *returns, void *stream);
+int uavx_uw_clear_episode_stats(uavx_uw_handle *h, void *stream);
 int uavx_uw_get_state(uavx_uw_handle *h, const uavx_uw_state_view *dst, void *stream);
 int uavx_uw_set_state(uavx_uw_handle *h, const uavx_uw_state_view *src, void *stream);
 

@@ -66,6 +66,11 @@ class _UWState(ctypes.Structure):
                 ("steps", ctypes.c_void_p), ("episode", ctypes.c_void_p), ("vel_f32", ctypes.c_void_p)]
 
 
+class _UWEpisodeState(ctypes.Structure):
+    _fields_ = [("pending", ctypes.c_void_p), ("reached", ctypes.c_void_p), ("ep_return", ctypes.c_void_p),
+                ("fin_counts", ctypes.c_void_p), ("fin_return", ctypes.c_void_p)]
+
+
 class _MT(ctypes.Structure):
     _fields_ = [("mt", ctypes.c_uint32 * 624), ("idx", ctypes.c_int32)]
 
@@ -94,6 +99,10 @@ def lib():
         L.uavo_step_ex.restype = None
         L.uavo_fold_episode.argtypes = [vp, vp, i64]
         L.uavo_fold_episode.restype = None
+        L.uavo_uw_fold_episode.argtypes = [vp, vp, i64]
+        L.uavo_uw_fold_episode.restype = None
+        L.uavo_uw_step_ex.argtypes = [vp, vp, vp, i32, i32, u32, i32, u64, i64, vp, i32, vp, vp, vp, vp, vp, i32]
+        L.uavo_uw_step_ex.restype = None
         L.uavo_uw_reset_mt.argtypes = [vp, vp, i64, vp]
         L.uavo_uw_reset_philox.argtypes = [vp, vp, vp, u64, i64, i32]
         L.uavo_uw_observe.argtypes = [vp, vp, vp, i32]
@@ -233,6 +242,13 @@ class OracleSingle:
         self.vel_f32 = np.zeros((E,), np.uint8)
         self._st = _UWState(E, _p(self.loc), _p(self.vel), _p(self.tgt), _p(self.init_d), _p(self.prev_d),
                             _p(self.steps), _p(self.episode), _p(self.vel_f32))
+        self.pending = np.zeros((E,), np.uint8)
+        self.reached = np.zeros((E,), np.uint8)
+        self.ep_return = np.zeros((E,), np.float32)
+        self.fin_counts = np.zeros((E, 4), np.uint32)
+        self.fin_return = np.zeros((E,), np.float32)
+        self._ep = _UWEpisodeState(_p(self.pending), _p(self.reached), _p(self.ep_return), _p(self.fin_counts),
+                                   _p(self.fin_return))
 
     def get_state(self):
         return dict(loc=self.loc.astype(np.float32), vel=self.vel.copy(), tgt=self.tgt.astype(np.float32),
@@ -246,8 +262,28 @@ class OracleSingle:
     def reset_mt(self, stream, env=0):
         lib().uavo_uw_reset_mt(ctypes.byref(self.cfg), ctypes.byref(self._st), env, ctypes.byref(stream._g))
 
+    def step_ex(self, actions, polar=False, auto_reset=False, step_cap=0, track_returns=True, seed=0, env_offset=0,
+                action_is_f32=None):
+        arr = np.asarray(actions)
+        if action_is_f32 is None:
+            action_is_f32 = arr.dtype == np.float32
+        a = np.ascontiguousarray(arr.astype(np.float64).reshape(self.E, 2))
+        obs = np.empty((self.E, UW_OBS_DIM), np.float64)
+        rew = np.empty((self.E,), np.float64)
+        done = np.empty((self.E,), np.uint8)
+        info = np.empty((self.E,), np.float64)
+        rmask = np.zeros((self.E,), np.uint8)
+        lib().uavo_uw_step_ex(ctypes.byref(self.cfg), ctypes.byref(self._st), ctypes.byref(self._ep), int(bool(polar)),
+                              int(bool(auto_reset)), int(step_cap), int(bool(track_returns)), int(seed), int(env_offset),
+                              _p(a), int(bool(action_is_f32)), _p(obs), _p(rew), _p(done), _p(info), _p(rmask),
+                              self.nthreads)
+        return obs, rew, done, info, rmask
+
     def reset_philox(self, seed, mask=None, env_offset=0):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        for e in range(self.E):
+            if m is None or m[e]:
+                lib().uavo_uw_fold_episode(ctypes.byref(self._st), ctypes.byref(self._ep), e)
         lib().uavo_uw_reset_philox(ctypes.byref(self.cfg), ctypes.byref(self._st),
                                    None if m is None else _p(m), int(seed), int(env_offset), self.nthreads)
 
@@ -267,4 +303,5 @@ class OracleSingle:
         info = np.empty((self.E,), np.float64)
         lib().uavo_uw_step(ctypes.byref(self.cfg), ctypes.byref(self._st), _p(a), int(bool(action_is_f32)),
                            _p(obs), _p(rew), _p(done), _p(info), self.nthreads)
+        self.reached[:] = info < 0.5
         return obs, rew, done, info

@@ -610,3 +610,51 @@ void uavo_uw_step(const uavo_uw_config *cfg, uavo_uw_state *st, const double *ac
     for (int64_t e = 0; e < st->num_envs; e++)
         uw_step_env(cfg, st, e, actions, action_is_f32, obs, reward, done, info_distance);
 }
+
+/* ---- uavx_uw_step_ex restatement ---- */
+void uavo_uw_fold_episode(uavo_uw_state *st, uavo_uw_episode_state *ep, int64_t e) {
+    if (st->steps[e] != 0) {
+        ep->fin_counts[4 * e + 0] += 1;
+        ep->fin_counts[4 * e + 1] += st->steps[e];
+        ep->fin_counts[4 * e + 2] += ep->reached[e] ? 1u : 0u;
+        ep->fin_return[e] += ep->ep_return[e];
+    }
+    ep->ep_return[e] = 0.f;
+    ep->pending[e] = 0;
+}
+
+void uavo_uw_step_ex(const uavo_uw_config *cfg, uavo_uw_state *st, uavo_uw_episode_state *ep, int action_mode,
+                     int auto_reset, uint32_t step_cap, int track_returns, uint64_t seed, int64_t env_offset,
+                     const double *actions, int action_is_f32, double *obs, double *reward, uint8_t *done,
+                     double *info_distance, uint8_t *reset_mask, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) {
+        if (ep->pending[e]) {
+            draw_src s;
+            memset(&s, 0, sizeof s);
+            uint64_t ge = (uint64_t)(env_offset + e);
+            s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
+            s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
+            s.episode = st->episode[e];
+            uavo_uw_fold_episode(st, ep, e);
+            uw_reset_env(cfg, st, e, &s);
+            st->episode[e] += 1;
+            uw_observe_env(cfg, st, e, obs + e * UAVO_UW_OBS_DIM);
+            reward[e] = 0.0; done[e] = 0; info_distance[e] = st->init_d[e];
+            if (reset_mask) reset_mask[e] = 1;
+            continue;
+        }
+        double act[2] = {actions[2 * e], actions[2 * e + 1]};
+        int is_f32 = action_is_f32;
+        if (action_mode == 1) { /* test_sac.py:77-80 in float32: v = (a0/2+0.5)*high[0], theta = a1*pi */
+            uavo_polar_to_command((float)act[0], (float)act[1], (float)cfg->max_speed, act);
+            is_f32 = 1;
+        }
+        uw_step_env(cfg, st, e, act - 2 * e, is_f32, obs, reward, done, info_distance);
+        ep->reached[e] = (uint8_t)(info_distance[e] < 0.5);
+        int ended = (auto_reset && done[e]) || (step_cap != 0 && st->steps[e] >= step_cap);
+        ep->pending[e] = (uint8_t)(ended ? 1 : 0);
+        if (track_returns) ep->ep_return[e] += (float)reward[e];
+        if (reset_mask) reset_mask[e] = 0;
+    }
+}

@@ -121,6 +121,20 @@ typedef struct {
     uint8_t *vel_f32; /* [E] 1 while velocity is still the float32 array drawn by reset (UW:122) */
 } uavo_uw_state;
 
+/* uavx_uw_step_ex restatement (test_sac.py:62-109 around env.step): NEW semantics, see uavo_step_ex. */
+typedef struct {
+    uint8_t *pending;      /* [E] */
+    uint8_t *reached;      /* [E] the last step ended at the target (UW:159) */
+    float *ep_return;      /* [E] */
+    uint32_t *fin_counts;  /* [E*4] episodes, steps, episodes ended at the target, 0 */
+    float *fin_return;     /* [E] */
+} uavo_uw_episode_state;
+void uavo_uw_fold_episode(uavo_uw_state *st, uavo_uw_episode_state *ep, int64_t env);
+void uavo_uw_step_ex(const uavo_uw_config *cfg, uavo_uw_state *st, uavo_uw_episode_state *ep, int action_mode,
+                     int auto_reset, uint32_t step_cap, int track_returns, uint64_t seed, int64_t env_offset,
+                     const double *actions, int action_is_f32, double *obs, double *reward, uint8_t *done,
+                     double *info_distance, uint8_t *reset_mask, int nthreads);
+
 void uavo_uw_reset_mt(const uavo_uw_config *cfg, uavo_uw_state *st, int64_t env, uavo_mt *g);
 void uavo_uw_reset_philox(const uavo_uw_config *cfg, uavo_uw_state *st, const uint8_t *mask,
                           uint64_t seed, int64_t env_offset, int nthreads);

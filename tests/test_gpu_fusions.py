@@ -233,3 +233,52 @@ def test_rgb_array_render(amd):
     assert img.shape == (800, 800, 3) and img.dtype == np.uint8
     assert (img != 255).any() and (img == 255).mean() > 0.8
     env.close()
+
+
+@pytest.mark.parametrize("polar,cap", [(False, 0), (True, 60), (True, 0)])
+def test_uw_step_ex_auto_reset_vs_oracle(amd, oracle_mod, polar, cap):
+    """UAVWorld2D: fused conversion / next-step auto-reset / episode statistics vs the oracle restatement."""
+    E = 4000
+    env = amd.BatchedUAVWorld2D(E, seed=31, env_offset=9)
+    orc = oracle_mod.OracleSingle(num_envs=E, nthreads=8)
+    env.reset()
+    orc.reset_philox(31, env_offset=9)
+    rng = np.random.default_rng(6)
+    resets = 0
+    for t in range(220):
+        d = orc.tgt - orc.loc
+        dist = np.linalg.norm(d, axis=-1, keepdims=True)
+        cmd = d / np.maximum(dist, 1e-9) * np.minimum(9.0, np.sqrt(4.0 * dist)) + rng.normal(0, 0.5, size=d.shape)
+        if polar:  # express the same command as a policy output in [-1,1]^2 (float32)
+            sp = np.clip(np.linalg.norm(cmd, axis=-1) / 12.0, 0, 1)
+            act = np.stack([sp * 2 - 1, np.arctan2(cmd[:, 1], cmd[:, 0]) / np.pi], axis=-1).astype(np.float32)
+        else:
+            act = cmd.astype(np.float32) if t % 2 else cmd
+        og, rg, dg, info = env.step_ex(act, polar=polar, auto_reset=True, step_cap=cap)
+        oo, ro, do, io, rm = orc.step_ex(act, polar=polar, auto_reset=True, step_cap=cap, seed=31, env_offset=9)
+        ctx = f"step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm, err_msg=ctx)
+        np.testing.assert_array_equal(_np(dg).astype(np.uint8), do, err_msg=ctx)
+        resets += int(rm.sum())
+        st = env.get_state()
+        np.testing.assert_array_equal(_np(st["loc"]), orc.loc.astype(np.float32), err_msg=ctx)
+        np.testing.assert_array_equal(_np(st["vel"]), orc.vel, err_msg=ctx)
+        np.testing.assert_array_equal(_np(st["tgt"]), orc.tgt.astype(np.float32), err_msg=ctx)
+        np.testing.assert_array_equal(_np(st["counters"])[:, 0], orc.steps, err_msg=ctx)
+        np.testing.assert_array_equal(_np(st["counters"])[:, 1], orc.episode, err_msg=ctx)
+        assert obs_err(_np(og), oo, (1, 3)) <= TOL, ctx
+        tol_r = np.maximum(TOL, np.spacing(np.abs(ro).astype(np.float32)).astype(np.float64))
+        assert (np.abs(_np(rg) - ro) <= tol_r).all(), ctx
+        np.testing.assert_array_equal(_np(info["distance"]), io.astype(np.float32), err_msg=ctx)
+    assert resets > E // 10
+    stats = {k: _np(v) for k, v in env.episode_stats().items()}
+    np.testing.assert_array_equal(stats["episodes"], orc.fin_counts[:, 0])
+    np.testing.assert_array_equal(stats["steps"], orc.fin_counts[:, 1])
+    np.testing.assert_array_equal(stats["reached"], orc.fin_counts[:, 2])
+    np.testing.assert_allclose(stats["returns"], orc.fin_return, rtol=1e-5, atol=0.05)
+    assert stats["reached"].sum() > 0
+    env.reset()
+    orc.reset_philox(31, env_offset=9)
+    np.testing.assert_array_equal(_np(env.episode_stats()["episodes"]), orc.fin_counts[:, 0])
+    np.testing.assert_array_equal(_np(env.episode_stats()["reached"]), orc.fin_counts[:, 2])
+    env.close()
