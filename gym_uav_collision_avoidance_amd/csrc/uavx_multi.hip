@@ -179,8 +179,8 @@ struct Neigh {
 };
 
 template <int NT, bool STEP>
-__device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
-                                                 float ny) {
+__device__ __forceinline__ Neigh scan_neighbours_exact(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
+                                                       float ny) {
     const int N = NT ? NT : p.N;
     Neigh r;
     r.d1 = r.d2 = INFINITY;
@@ -224,6 +224,66 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
             visit(j, row[j]);
         }
     }
+    return r;
+}
+
+// Same result with N-1 -> 3 square roots, for N > 4 (the scan is O(N) per lane, and the IEEE sqrt is its
+// most expensive part): keep the THREE smallest squared distances (ties by index, like the exact scan) and
+// take roots only of those.  sqrtf is monotone, so the order by distance can differ from the order by
+// squared distance only where two roots round to the same float: {1,2} are swapped back into index order
+// if their roots tie, and if the third root ties with the second (the only way an agent outside the top
+// two could belong there) the wave falls back to the exact scan.  Bit-identical to scan_neighbours_exact.
+template <int NT, bool STEP>
+__device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
+                                                 float ny) {
+    if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);
+    const int N = NT ? NT : p.N;
+    if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);  // <= 4 others: nothing to save
+    const float4 *row = &lds.pos[m.wib][m.base];
+    float s1 = INFINITY, s2 = INFINITY, s3 = INFINITY, step_min = INFINITY;
+    int j1 = -1, j2 = -1, j3 = -1;
+    auto visit = [&](int j, float4 q) {
+        const float dxn = q.z - nx, dyn = q.w - ny;
+        const float ax = dxn * dxn, ay = dyn * dyn;
+        float sn = ax + ay;
+        if (STEP) {
+            const float dxo = q.x - nx, dyo = q.y - ny;
+            const float bx = dxo * dxo, by = dyo * dyo;
+            const float so = bx + by;
+            const float ss = (j < m.i) ? sn : so;
+            step_min = fminf(step_min, (ss < p.sq_sense) ? ss : INFINITY);
+        }
+        sn = (sn < p.sq_sense) ? sn : INFINITY;  // AG:52
+        const bool lt1 = sn < s1, lt2 = sn < s2, lt3 = sn < s3;
+        s3 = lt2 ? s2 : (lt3 ? sn : s3);  j3 = lt2 ? j2 : (lt3 ? j : j3);
+        s2 = lt1 ? s1 : (lt2 ? sn : s2);  j2 = lt1 ? j1 : (lt2 ? j : j2);
+        s1 = lt1 ? sn : s1;               j1 = lt1 ? j : j1;
+    };
+    if (NT) {  // compile-time N: all LDS reads issued before the first use
+        constexpr int M = NT > 1 ? NT - 1 : 1;
+        float4 q[M];
+        int js[M];
+#pragma unroll
+        for (int k = 0; k < NT - 1; k++) {
+            js[k] = k + (k >= m.i ? 1 : 0);  // ascending over the other agents, self skipped
+            q[k] = row[js[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < NT - 1; k++) visit(js[k], q[k]);
+    } else {
+#pragma unroll 2
+        for (int k = 0; k < N - 1; k++) {
+            const int j = k + (k >= m.i ? 1 : 0);
+            visit(j, row[j]);
+        }
+    }
+    Neigh r;
+    r.step_sq_min = step_min;
+    float d1 = sqrtf(s1), d2 = sqrtf(s2);
+    const float d3 = sqrtf(s3);
+    if (__any(d3 == d2 && d2 < INFINITY)) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);
+    if (d1 == d2 && j2 < j1 && j2 >= 0) { const int t = j1; j1 = j2; j2 = t; }  // s1 < s2 whose roots tie: index order (AG:62)
+    r.d1 = d1; r.d2 = d2; r.j1 = (s1 < INFINITY) ? j1 : -1; r.j2 = (s2 < INFINITY) ? j2 : -1;
     return r;
 }
 
