@@ -78,6 +78,11 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
+        try:  # not built yet (fresh checkout): compile the HIP library once; this is a build, not a fallback
+            build()
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {CSRC}` "
             "(or __graft_entry__.build()). There is no CPU fallback for the env step path.")
