@@ -70,11 +70,13 @@ struct MultiParams {
     // env.steps (MUW:238) = wave_steps[wave of the env] - steps_base[env]: a step launch bumps ONE counter per
     // wavefront (every env of a wave is stepped by the same launches) instead of one word per env; reset and
     // set_state move the env's base (A/B at 65536x4: per-env counter updates cost 3 % of the launch).
-    uint32_t *wave_steps, *steps_base;
-    uint32_t *reach, *coll, *episode;
+    uint32_t *wave_steps;
+    // per-env record, ONE 16-byte word (one load / one store per env in step_ex instead of four / three):
+    //   .x steps_base   .y episode index (bits 0..30) | episode-ended flag (bit 31)   .z,.w running episode
+    //   return of agent 0 and evaluation score sum_i r_i*(1-done_i) (float bits)
+    uint4 *env_rec;
+    uint32_t *reach, *coll;
     // episode bookkeeping (uavx_step_ex / uavx_reset)
-    uint8_t *pending;   // [E] env ended its episode: re-initialise it at the next step_ex call
-    float2 *ep_run;     // [E] running {agent-0 return, sum_i r_i*(1-done_i)} of the current episode
     uint4 *fin_counts;  // [E] over ended episodes: {episodes, steps, target_reach_count, collision_count}
     float2 *fin_returns;  // [E] over ended episodes: {agent-0 return sum, evaluation score sum}
 };
@@ -492,54 +494,56 @@ __device__ __forceinline__ bool too_close(const MultiParams &p, float ax, float 
     return xx + yy <= p.sq_two_r;
 }
 
+// MUW:116-155 for the envs of this wave flagged `go` (all lanes of an env agree), wave-cooperative.
+// Every lane draws its agent's first start/target candidates with ONE Philox call.  The reference's
+// sequential accept/reject chain (agent i keeps the first candidate that is clear of the ACCEPTED points of
+// agents j < i, MUW:127-153) is replayed without a per-agent turn loop: all lanes test their current
+// candidate against the lower-indexed ones at once; if any clash, only the LOWEST-indexed clashing agent of
+// each env redraws (everyone below it is already final, everyone above it still holds its first candidate),
+// and the test repeats.  With no clash — the common case, probability ~N^2*pi*R^2/area — that is one pass for
+// the start points and one for the targets; each clash costs one more pass.  (A per-agent turn loop here
+// made 6 % of the resets take thousands of cycles, and with ~100 resets per launch that long tail was in
+// EVERY launch: +3 us at 65 536 x 4.)  Same distribution as the reference; the stream layout is
+// reset_candidates(), restated by the CPU test oracle.
 template <int NT>
 __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, Lds &lds, bool go,
                                                 uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s) {
     const int N = NT ? NT : p.N;
     float4 *row = &lds.pos[m.wib][m.base];
     const uint64_t ge = (uint64_t)p.env_offset + m.e;
+    const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     ResetCandidates c = {0.f, 0.f, 0.f, 0.f};
     if (go) {
         c = reset_candidates(ge, m.i, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy);
         lds.pos[m.wib][m.lane] = make_float4(c.sx, c.sy, c.tx, c.ty);
     }
     wave_lds_sync();
-    bool clash = false;
-    if (go) {
-        clash = too_close(p, c.tx, c.ty, c.sx, c.sy);                                        // MUW:146
 #pragma unroll 1
-        for (int j = 0; j < m.i; j++) {
-            const float4 o = row[j];
-            clash = clash || too_close(p, o.x, o.y, c.sx, c.sy) || too_close(p, o.z, o.w, c.tx, c.ty);  // MUW:135,151
-        }
-    }
-    if (__ballot(clash) != 0ull) {  // rare: replay the chain sequentially, redrawing on clashes
-        wave_lds_sync();
-        uint32_t att[2] = {0u, 0u};
+    for (int phase = 0; phase < 2; phase++) {  // 0: start points MUW:126-137, 1: targets MUW:140-153
+        uint32_t attempt = 0;
 #pragma unroll 1
-        for (int phase = 0; phase < 2; phase++) {      // 0: start points MUW:126-137, 1: targets MUW:140-153
+        for (;;) {
+            bool clash = false;
+            if (go) {
+                const float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
+                clash = phase ? too_close(p, qx, qy, c.sx, c.sy) : false;                       // MUW:146
 #pragma unroll 1
-            for (int turn = 0; turn < N; turn++) {
-                if (go && m.i == turn) {
-                    bool bad = true;
-                    while (bad) {
-                        const float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
-                        bad = phase ? too_close(p, qx, qy, c.sx, c.sy) : false;              // MUW:146
-#pragma unroll 1
-                        for (int j = 0; j < turn && !bad; j++) {
-                            const float4 o = row[j];
-                            bad = too_close(p, phase ? o.z : o.x, phase ? o.w : o.y, qx, qy);  // MUW:135,151
-                        }
-                        if (bad) {
-                            const ResetCandidates r = reset_candidates(ge, m.i, ++att[phase], episode, k0, k1, p.lox,
-                                                                       p.loy, p.hix, p.hiy);
-                            if (phase) { c.tx = r.tx; c.ty = r.ty; } else { c.sx = r.sx; c.sy = r.sy; }
-                        }
-                    }
-                    if (phase) { row[turn].z = c.tx; row[turn].w = c.ty; } else { row[turn].x = c.sx; row[turn].y = c.sy; }
+                for (int j = 0; j < m.i; j++) {
+                    const float4 o = row[j];
+                    clash = clash || too_close(p, phase ? o.z : o.x, phase ? o.w : o.y, qx, qy);  // MUW:135,151
                 }
-                wave_lds_sync();
             }
+            const unsigned long long bits = __ballot(clash);
+            if (bits == 0ull) break;
+            const unsigned long long mine = (bits >> m.base) & group;     // clashing agents of my env
+            const bool redraw = go && mine != 0ull && m.i == (int)__builtin_ctzll(mine);
+            wave_lds_sync();
+            if (redraw) {  // the lowest-indexed clashing agent takes its next candidate
+                const ResetCandidates r = reset_candidates(ge, m.i, ++attempt, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy);
+                if (phase) { c.tx = r.tx; c.ty = r.ty; row[m.i].z = c.tx; row[m.i].w = c.ty; }
+                else { c.sx = r.sx; c.sy = r.sy; row[m.i].x = c.sx; row[m.i].y = c.sy; }
+            }
+            wave_lds_sync();
         }
     }
     wave_lds_sync();
@@ -552,27 +556,27 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
 
 // An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation
 // loop reads (test_sac_multi.py:157,164-165) and clear the running values.  One lane per env.
+constexpr uint32_t kRecEnded = 0x80000000u;  // env_rec.y bit 31: episode ended, re-initialise at the next step_ex
+
 struct EpisodeFold {
-    uint4 c; float2 f, run; uint32_t reach, coll;
+    uint4 c; float2 f; uint32_t reach, coll;
 };
 __device__ __forceinline__ EpisodeFold fold_load(const MultiParams &p, uint32_t e) {  // all loads up front: one latency
     EpisodeFold v;
-    v.c = p.fin_counts[e]; v.f = p.fin_returns[e]; v.run = p.ep_run[e];
+    v.c = p.fin_counts[e]; v.f = p.fin_returns[e];
     v.reach = p.reach[e]; v.coll = p.coll[e];
     return v;
 }
-__device__ __forceinline__ void fold_store(const MultiParams &p, uint32_t e, uint32_t steps, uint32_t episode,
-                                           EpisodeFold v) {
+// An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation loop reads
+// (test_sac_multi.py:157,164-165) and clear them (MUW:167-168).  One lane per env; the caller rewrites env_rec.
+__device__ __forceinline__ void fold_store(const MultiParams &p, uint32_t e, uint32_t steps, float2 run, EpisodeFold v) {
     if (steps != 0) {
         v.c.x += 1; v.c.y += steps; v.c.z += v.reach; v.c.w += v.coll;
-        v.f.x += v.run.x; v.f.y += v.run.y;
+        v.f.x += run.x; v.f.y += run.y;
         p.fin_counts[e] = v.c;
         p.fin_returns[e] = v.f;
     }
-    p.ep_run[e] = make_float2(0.f, 0.f);
     p.reach[e] = 0; p.coll[e] = 0;  // MUW:167-168
-    p.episode[e] = episode + 1;
-    p.pending[e] = 0;
 }
 
 // test_sac_multi.py:77-80 in float32: a in [-1,1]^2 -> velocity command.
@@ -608,19 +612,12 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
 #endif
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
-    uint32_t steps_v = 0, episode = 0, wave_count = 0;
-    bool do_reset = false;
-    float2 run = make_float2(0.f, 0.f);
-    // The per-env words are loaded FIRST and the 52 B of agent state after them: vmcnt retires in issue
-    // order, so the (rare) re-initialisation below can start as soon as the small loads are back and runs
-    // underneath the state loads of the launch-wide read burst instead of extending the wave's tail.
-    if (m.active) {
-        do_reset = p.pending[m.e] != 0;
-        wave_count = p.wave_steps[m.wave];
-        steps_v = wave_count - p.steps_base[m.e];
-        episode = p.episode[m.e];
-        if (x.track_returns && m.i == 0) run = p.ep_run[m.e];
-    }
+    // The env record is loaded FIRST and the 48 B of agent state after it: vmcnt retires in issue order, so the
+    // (rare) re-initialisation below can start as soon as the small load is back and runs underneath the
+    // state loads of the launch-wide read burst.  The wave's step counter comes through the scalar cache.
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (m.active) rec = p.env_rec[m.e];
+    const uint32_t wave_count = p.wave_steps[__builtin_amdgcn_readfirstlane(m.wave)];
     __builtin_amdgcn_sched_barrier(0);
     AgentRegs ld = {};
     if (m.active) {
@@ -628,17 +625,22 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         load_action<ACT64>(actions, m.a, ax, ay);
     }
     __builtin_amdgcn_sched_barrier(0);
+    const bool do_reset = (rec.y & kRecEnded) != 0;
+    const uint32_t episode = rec.y & ~kRecEnded;
+    uint32_t steps_v = wave_count - rec.x;
+    float2 run = make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w));
     AgentRegs fresh = {};
     EpisodeFold fold = {};
     const uint32_t ended_steps = steps_v;
+    const float2 ended_run = run;
     const bool wave_resets = __ballot(do_reset) != 0ull;
     STAMP(1);
     if (wave_resets) {  // wave-uniform: at least one env of this wave starts a new episode
-        // the statistics words are requested here and consumed after the step (fold_store at the end), so
-        // their round trip overlaps the step arithmetic instead of stalling this wave
-        // A wave that re-initialises an env has ~400 more instructions to issue than its three SIMD
-        // mates and would finish last (launch time = slowest wave): let it issue ahead of them for the
-        // rest of its life; the mates lose only issue slots they had to spare.
+        // A wave that re-initialises an env has a few hundred more instructions to issue than its three SIMD
+        // mates and would finish last (launch time = slowest wave): let it issue ahead of them for the rest
+        // of its life; the mates lose only issue slots they had to spare.  The statistics words are
+        // requested here and consumed after the step (fold_store at the end): their round trip overlaps the
+        // step arithmetic.
         __builtin_amdgcn_s_setprio(3);
         if (do_reset && m.i == 0) fold = fold_load(p, m.e);
         reset_envs_wave<NT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, fresh);
@@ -671,26 +673,28 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
+        if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
         if (m.i == 0) {
-            const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;  // MUW:238
-            bool ended = (x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
-                         (x.reset_policy == UAVX_RESET_ALL_DONE && all_done) ||
-                         (x.step_cap != 0 && steps_next >= x.step_cap);
-            ended = ended && !do_reset;
-            if (do_reset) p.steps_base[m.e] = wave_count + 1u;   // steps == 0 after this launch (MUW:166)
-            if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave
-            p.pending[m.e] = ended ? 1 : 0;
+            const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;
+            const bool ended = ((x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
+                                (x.reset_policy == UAVX_RESET_ALL_DONE && all_done) ||
+                                (x.step_cap != 0 && steps_next >= x.step_cap)) && !do_reset;
             if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
-            if (do_reset) {  // fold the ended episode; pending/ep_run written below supersede fold_store's
-                fold_store(p, m.e, ended_steps, episode, fold);
+            uint4 out = rec;
+            if (do_reset) {  // fold the ended episode, start the new one: steps == 0 after this launch (MUW:166)
+                fold_store(p, m.e, ended_steps, ended_run, fold);
+                out.x = wave_count + 1u;
+                out.y = episode + 1u;
             }
+            out.y = (out.y & ~kRecEnded) | (ended ? kRecEnded : 0u);
             if (x.track_returns) {
                 float score = 0.f;
                 for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.base + j];
                 run.x += do_reset ? 0.f : rew;               // test_sac_multi.py:106 score += rewards[0]
                 run.y += score;
-                p.ep_run[m.e] = run;
             }
+            out.z = __float_as_uint(run.x); out.w = __float_as_uint(run.y);
+            if (out.x != rec.x || out.y != rec.y || out.z != rec.z || out.w != rec.w) p.env_rec[m.e] = out;
         }
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
@@ -779,7 +783,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
     const bool go = m.active && (!mask || mask[m.e] != 0);
     if (__ballot(go) == 0ull) return;
     AgentRegs s = {};
-    const uint32_t episode = go ? p.episode[m.e] : 0u;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (go) rec = p.env_rec[m.e];
+    const uint32_t episode = rec.y & ~kRecEnded;
     reset_envs_wave<NT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
     if (go) {
         p.pos[m.a] = make_float2(s.x, s.y);
@@ -787,8 +793,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
         p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, 0u};
         if (m.i == 0) {
             const uint32_t wc = p.wave_steps[m.wave];
-            fold_store(p, m.e, wc - p.steps_base[m.e], episode, fold_load(p, m.e));
-            p.steps_base[m.e] = wc;  // MUW:166 steps = 0
+            fold_store(p, m.e, wc - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold_load(p, m.e));
+            p.env_rec[m.e] = make_uint4(wc, episode + 1u, 0u, 0u);  // MUW:166 steps = 0, new episode, no running return
         }
     }
 }
@@ -825,8 +831,9 @@ __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_s
         if (v.init_d) v.init_d[a] = g.init_d;
     }
     if (a < p.E && v.counters) {
-        v.counters[4 * a + 0] = p.wave_steps[a / p.epw] - p.steps_base[a]; v.counters[4 * a + 1] = p.reach[a];
-        v.counters[4 * a + 2] = p.coll[a];  v.counters[4 * a + 3] = p.episode[a];
+        const uint4 rec = p.env_rec[a];
+        v.counters[4 * a + 0] = p.wave_steps[a / p.epw] - rec.x; v.counters[4 * a + 1] = p.reach[a];
+        v.counters[4 * a + 2] = p.coll[a];  v.counters[4 * a + 3] = rec.y & ~kRecEnded;
     }
 }
 
@@ -858,8 +865,11 @@ __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_s
         if (v.vel) p.vel[a] = make_double2(v.vel[2 * a], v.vel[2 * a + 1]);
     }
     if (a < p.E && v.counters) {
-        p.steps_base[a] = p.wave_steps[a / p.epw] - v.counters[4 * a + 0]; p.reach[a] = v.counters[4 * a + 1];
-        p.coll[a] = v.counters[4 * a + 2];  p.episode[a] = v.counters[4 * a + 3];
+        uint4 rec = p.env_rec[a];
+        rec.x = p.wave_steps[a / p.epw] - v.counters[4 * a + 0];
+        rec.y = (rec.y & kRecEnded) | (v.counters[4 * a + 3] & ~kRecEnded);
+        p.env_rec[a] = rec;
+        p.reach[a] = v.counters[4 * a + 1]; p.coll[a] = v.counters[4 * a + 2];
     }
 }
 
@@ -1051,13 +1061,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_ovr = off;  off = align_up(off + A * sizeof(float), 256);
     const size_t o_vel = off;  off = align_up(off + A * sizeof(double2), 256);
     const size_t o_goal = off; off = align_up(off + A * sizeof(Goal), 256);
-    const size_t o_steps = off; off = align_up(off + E * 4, 256);
+    const size_t o_steps = off; off = align_up(off + E * sizeof(uint4), 256);
     const size_t o_wsteps = off; off = align_up(off + ((E + (kWave / N) - 1) / (kWave / N)) * 4, 256);
     const size_t o_reach = off; off = align_up(off + E * 4, 256);
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
-    const size_t o_epi = off;   off = align_up(off + E * 4, 256);
-    const size_t o_pend = off;  off = align_up(off + E, 256);
-    const size_t o_run = off;   off = align_up(off + E * sizeof(float2), 256);
     const size_t o_finc = off;  off = align_up(off + E * sizeof(uint4), 256);
     const size_t o_finr = off;  off = align_up(off + E * sizeof(float2), 256);
     e = hipMalloc(&h->slab, off);
@@ -1069,13 +1076,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.prev_ovr = reinterpret_cast<float *>(b + o_ovr);
     p.vel = reinterpret_cast<double2 *>(b + o_vel);
     p.goal = reinterpret_cast<Goal *>(b + o_goal);
-    p.steps_base = reinterpret_cast<uint32_t *>(b + o_steps);
+    p.env_rec = reinterpret_cast<uint4 *>(b + o_steps);
     p.wave_steps = reinterpret_cast<uint32_t *>(b + o_wsteps);
     p.reach = reinterpret_cast<uint32_t *>(b + o_reach);
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
-    p.episode = reinterpret_cast<uint32_t *>(b + o_epi);
-    p.pending = reinterpret_cast<uint8_t *>(b + o_pend);
-    p.ep_run = reinterpret_cast<float2 *>(b + o_run);
     p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
     p.fin_returns = reinterpret_cast<float2 *>(b + o_finr);
     *out = h;

@@ -20,12 +20,10 @@ for k in range(1):
     env.step_ex(cart[k % R], track_returns=False, auto_reset="agent0_done")
 L.uavx_debug_stamps(buf, ctypes.byref(n))
 a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[: n.value].astype(np.int64)
-t0 = a[:, 0].min()
-for kind in (0, 1):
+names = {0: "normal waves", 1: "waves folding a fresh env", 2: "waves drawing a new layout", 3: "both"}
+for kind in (0, 1, 2, 3):
     r = a[a[:, 6] == kind]
     if len(r) == 0: continue
-    rel = r[:, :6] - t0
-    print("reset waves" if kind else "normal waves", len(r), "median stamps (cycles since first wave start):",
-          np.median(rel, axis=0).astype(int).tolist(), " max end:", int(rel[:, 5].max()))
     d = np.diff(r[:, :6], axis=1)
-    print("   median segment cycles [loads->ballot, reset, select, step, epilogue]:", np.median(d, axis=0).astype(int).tolist())
+    print(names[kind], len(r), "median segment cycles [loads->ballot, fold_load issue, polar, step, stores(+draw)]:",
+          np.median(d, axis=0).astype(int).tolist(), " total", int(np.median(r[:, 5] - r[:, 0])), " max total", int((r[:, 5] - r[:, 0]).max()))
