@@ -74,6 +74,27 @@ __device__ __forceinline__ float wrap_pi(float x) {
     return fmaf(-k, kTwoPi, x);
 }
 
+// atan2f for finite inputs, ~2 ulp: octant reduction + Cephes atanf polynomial on |t| <= tan(pi/8).
+// (Results only feed float32 observation/reward features that are compared at 1e-5.)
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const bool big = mn > 0.41421356237f * mx;
+    const float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    den = (mx == 0.f) ? 1.f : den;              // atan2(0, 0) = 0
+    const float t = num * __builtin_amdgcn_rcpf(den);
+    const float z = t * t;
+    float pl = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    pl = fmaf(pl, z, 1.99777106478e-1f);
+    pl = fmaf(pl, z, -3.33329491539e-1f);
+    float r = fmaf(pl * z, t, t);
+    r = big ? r + 0.78539816339744830962f : r;
+    r = (ay > ax) ? 1.57079632679489661923f - r : r;
+    r = (x < 0.f) ? kPi - r : r;
+    return copysignf(r, y);
+}
+
 // x / tau, correctly rounded, without the hardware division sequence: with r = RN(1/tau) the
 // Markstein form q0 = RN(x*r), rem = fma(-q0, tau, x) (exact), q = fma(rem, r, q0) returns the IEEE
 // quotient (checked against x/tau on 2.1e9 samples for tau = 0.02 and six other steps; uavx_create

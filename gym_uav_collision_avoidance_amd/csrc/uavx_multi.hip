@@ -289,27 +289,6 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
     return r;
 }
 
-// atan2f for finite inputs, ~2 ulp: octant reduction + Cephes atanf polynomial on |t| <= tan(pi/8).
-// (Results only feed float32 observation/reward features that are compared at 1e-5.)
-__device__ __forceinline__ float atan2_fast(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const bool big = mn > 0.41421356237f * mx;
-    const float num = big ? mn - mx : mn;
-    float den = big ? mn + mx : mx;
-    den = (mx == 0.f) ? 1.f : den;              // atan2(0, 0) = 0
-    const float t = num * __builtin_amdgcn_rcpf(den);
-    const float z = t * t;
-    float pl = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
-    pl = fmaf(pl, z, 1.99777106478e-1f);
-    pl = fmaf(pl, z, -3.33329491539e-1f);
-    float r = fmaf(pl * z, t, t);
-    r = big ? r + 0.78539816339744830962f : r;
-    r = (ay > ax) ? 1.57079632679489661923f - r : r;
-    r = (x < 0.f) ? kPi - r : r;
-    return copysignf(r, y);
-}
-
 // MUW:60-109 in float32 (angles compared on the circle; see DESIGN.md numerics).
 __device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap &m, const Lds &lds, const Neigh &nb,
                                              float nx, float ny, float speed, float theta, float dist_t, float dth,
@@ -915,7 +894,8 @@ double sq_threshold(double lim) {
 // div_tau() on the device replaces x/tau by a reciprocal + two fma; confirm on this tau that the
 // form returns the IEEE quotient (differences a - v of the magnitudes the kinematics produce, plus
 // the band |x| < amax*tau where the quotient is not clipped away).
-bool recip_division_exact(double tau) {
+}  // namespace
+bool uavx_recip_division_exact(double tau) {
     const double r = 1.0 / tau;
     uint64_t s0 = 0x9E3779B97F4A7C15ull, s1 = 0xD1B54A32D192ED03ull;
     for (int i = 0; i < 100000; i++) {
@@ -930,6 +910,7 @@ bool recip_division_exact(double tau) {
     }
     return true;
 }
+namespace {
 
 // float32 limits for threshold tests on squared distances (host sqrtf is correctly rounded):
 // smallest s with sqrtf(s) >= lim   ->   sqrtf(s) <  lim  <=>  s <  result
@@ -1034,7 +1015,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const int N = cfg->num_agents;
     p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
     p.rtau = 1.0 / cfg->tau;
-    p.recip_ok = recip_division_exact(cfg->tau) ? 1 : 0;
+    p.recip_ok = uavx_recip_division_exact(cfg->tau) ? 1 : 0;
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
     p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
     p.speed_sq_lim = sq_threshold(0.2);

@@ -17,8 +17,9 @@
 namespace uavx {
 
 struct UwParams {
-    double tau, amax, vmax;
+    double tau, rtau, amax, vmax;  // rtau = RN(1/tau) for div_tau()
     double lox, loy, hix, hiy;
+    int recip_ok;
     float tau_f;       // float32(tau): UW:142 divides a float32 array by the python float
     float high0;       // float32(action_space.high[0]) = max_speed (test_sac.py:77)
     float inv_vmax;    // 1/max_speed[0]            UW:88
@@ -63,8 +64,8 @@ __device__ __forceinline__ void uw_step_env(const UwParams &p, UwRegs &s, double
         qx = (double)(((float)ax - (float)s.vx) / p.tau_f);
         qy = (double)(((float)ay - (float)s.vy) / p.tau_f);
     } else {
-        qx = (ax - s.vx) / p.tau;
-        qy = (ay - s.vy) / p.tau;
+        qx = div_tau(ax - s.vx, p.tau, p.rtau, p.recip_ok != 0);
+        qy = div_tau(ay - s.vy, p.tau, p.rtau, p.recip_ok != 0);
     }
     s.vx = clip64(s.vx + clip64(qx, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);  // UW:142-144
     s.vy = clip64(s.vy + clip64(qy, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);
@@ -73,8 +74,8 @@ __device__ __forceinline__ void uw_step_env(const UwParams &p, UwRegs &s, double
     const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);  // UW:149,162
     const float tdx = s.tx - s.x, tdy = s.ty - s.y;
     const float d = norm32(tdx, tdy);                        // UW:150
-    const float theta = atan2f((float)s.vy, (float)s.vx);    // UW:89
-    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);     // UW:155-156
+    const float theta = atan2_fast((float)s.vy, (float)s.vx);    // UW:89
+    const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);     // UW:155-156
     float r = 0.0f - 1.0f / s.init_d;                        // UW:152-153 (float32 under NEP 50)
     r = r + 10.0f * (s.prev_d - d);                          // UW:154
     r = r - 0.1f * fabsf(dth);                               // UW:157
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(kBlock) void uw_step_ex_kernel(UwParams p, UwExtra 
         uw_store(p, e, s);
         p.steps[e] = 0;                                                  // UW:131
         const float tdx = s.tx - s.x, tdy = s.ty - s.y;
-        const float theta = atan2f((float)s.vy, (float)s.vx);
-        obs_out[e] = uw_obs(p, norm32((float)s.vx, (float)s.vy), theta, s.init_d, wrap_pi(atan2f(tdy, tdx) - theta));
+        const float theta = atan2_fast((float)s.vy, (float)s.vx);
+        obs_out[e] = uw_obs(p, norm32((float)s.vx, (float)s.vy), theta, s.init_d, wrap_pi(atan2_fast(tdy, tdx) - theta));
         rew_out[e] = 0.f;
         done_out[e] = 0;
         if (info_out) info_out[e] = s.init_d;
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(kBlock) void uw_observe_kernel(UwParams p, float4 *
     const float4 d4 = p.dyn[e];
     const double2 v = p.vel[e];
     const float tdx = p.goal[3 * e] - d4.x, tdy = p.goal[3 * e + 1] - d4.y;
-    const float theta = atan2f((float)v.y, (float)v.x);
-    const float dth = wrap_pi(atan2f(tdy, tdx) - theta);
+    const float theta = atan2_fast((float)v.y, (float)v.x);
+    const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);
     const float speed = sqrtf((float)fma(v.y, v.y, v.x * v.x));
     obs_out[e] = uw_obs(p, speed, theta, norm32(tdx, tdy), dth);
 }
@@ -287,6 +288,8 @@ struct uavx_uw_handle {
     std::string err;
 };
 
+bool uavx_recip_division_exact(double tau);  // uavx_multi.hip
+
 namespace {
 
 int uw_fail(uavx_uw_handle *h, int code, const std::string &msg) {
@@ -336,6 +339,8 @@ int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offs
     UwParams &p = h->p;
     std::memset(&p, 0, sizeof p);
     p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
+    p.rtau = 1.0 / cfg->tau;
+    p.recip_ok = uavx_recip_division_exact(cfg->tau) ? 1 : 0;
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0; p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;
     p.tau_f = (float)cfg->tau;
     p.high0 = (float)cfg->max_speed;
