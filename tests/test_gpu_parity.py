@@ -452,3 +452,34 @@ def test_nonfinite_actions_propagate_like_numpy(amd, oracle_mod):
         assert np.isnan(_np(obs_g)[~finite]).any(axis=-1).all() if (~finite).any() else True
     assert np.isnan(orc.vel[3, 3]).any() and np.isnan(orc.vel[4, 0]).any() and np.isfinite(orc.vel[0, 1]).all()
     env.close()
+
+
+def test_side_stream_and_hip_array_interface(amd):
+    """Launches go to the caller's current HIP stream (no hidden sync), and any object that publishes
+    __hip_array_interface__ (same schema as the CUDA array interface) is accepted zero-copy as the action buffer."""
+    import torch
+    E, n = 4096, 4
+    a = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=12)
+    b = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=12)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    tape = (torch.rand((12, E, n, 2), generator=g) * 20 - 10).to(a.device)
+    side = torch.cuda.Stream(a.device)
+    side.wait_stream(torch.cuda.current_stream(a.device))
+    with torch.cuda.stream(side):
+        for t in range(12):
+            oa, ra, da, _ = a.step(tape[t])
+    side.synchronize()
+
+    class Foreign:  # a non-torch device buffer that only speaks __hip_array_interface__
+        def __init__(self, t):
+            self._keep = t
+            self.__hip_array_interface__ = amd.HipArray(t).__hip_array_interface__
+
+    for t in range(12):
+        ob, rb, db, _ = b.step(Foreign(tape[t]))
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    iface = amd.HipArray(oa).__hip_array_interface__
+    assert iface["data"][0] == oa.data_ptr() and iface["shape"] == (E, n, 10) and iface["typestr"] == "<f4"
+    a.close(); b.close()
