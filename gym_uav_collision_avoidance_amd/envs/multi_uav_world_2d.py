@@ -50,6 +50,19 @@ class MultiUAVWorld2D:
                                                 max_acceleration, self.tau))
         self.window = None
         self.clock = None
+        # One packed device buffer for a step's outputs (obs | rew | done) and one pinned host mirror: a step
+        # is one async H2D of the commands, one launch and ONE D2H instead of three .cpu() round trips.
+        n = num_agents
+        dev = b.device
+        self._pack = torch.zeros(n * 45 + 3, dtype=torch.uint8, device=dev)
+        self._obs_d = self._pack[: n * 40].view(torch.float32).view(1, n, 10)
+        self._rew_d = self._pack[n * 40: n * 44].view(torch.float32).view(1, n)
+        self._done_d = self._pack[n * 44: n * 45].view(1, n)
+        self._host = torch.zeros(n * 45 + 3, dtype=torch.uint8).pin_memory()
+        self._host_np = self._host.numpy()
+        self._act_host = torch.zeros((1, n, 2), dtype=torch.float64).pin_memory()
+        self._act_np = self._act_host.numpy()
+        self._act_d = torch.zeros((1, n, 2), dtype=torch.float64, device=dev)
 
     # -- counters live on the device (MUW:166-168,209,221,238) ----------------------------------------
     def _counter(self, k):
@@ -108,13 +121,20 @@ class MultiUAVWorld2D:
         return (obs, self._get_info()) if return_info else obs
 
     def step(self, n_action, evaluate=False):  # MUW:177
-        a = np.asarray([np.asarray(x, dtype=np.float64) for x in n_action], dtype=np.float64)
-        if a.shape != (self.num_agents, 2):
-            raise IndexError(f"n_action must hold {self.num_agents} actions of 2 components")
-        obs, rew, done, _ = self._batched.step(torch.from_numpy(a[None]).to(self._batched.device), evaluate=evaluate)
-        rew = rew[0].cpu().numpy()
-        done = done[0].cpu().numpy()
-        return (self._obs_list(obs), [float(r) for r in rew], [bool(d) for d in done], self._get_info())
+        n = self.num_agents
+        if len(n_action) != n:
+            raise IndexError(f"n_action must hold {n} actions of 2 components")
+        for i in range(n):
+            self._act_np[0, i] = n_action[i]        # float32 or float64 commands widen exactly
+        self._act_d.copy_(self._act_host, non_blocking=True)
+        self._batched.step(self._act_d, evaluate=evaluate, out=(self._obs_d, self._rew_d, self._done_d))
+        self._host.copy_(self._pack, non_blocking=True)
+        torch.cuda.current_stream(self._batched.device).synchronize()
+        h = self._host_np
+        obs = h[: n * 40].view(np.float32).reshape(n, 10)
+        rew = h[n * 40: n * 44].view(np.float32)
+        done = h[n * 44: n * 45]
+        return ([obs[i].copy() for i in range(n)], [float(r) for r in rew], [bool(d) for d in done], self._get_info())
 
     def render(self, mode="human"):
         """MUW:243-331.  mode="human" is a no-op (no display / pygame on a compute node, and the trainers call

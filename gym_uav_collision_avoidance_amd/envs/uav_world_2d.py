@@ -24,6 +24,14 @@ class UAVWorld2D:
         self.observation_space, self.action_space = b.observation_space, b.action_space
         self.window = None
         self.clock = None
+        # pinned staging for the commands and ONE device->host copy of (obs | rew | info | done) per step
+        dev = b.device
+        self._pack = torch.zeros(28, dtype=torch.uint8, device=dev)
+        self._host = torch.zeros(28, dtype=torch.uint8).pin_memory()
+        self._host_np = self._host.numpy()
+        self._act_host = {np.dtype(np.float32): torch.zeros((1, 2), dtype=torch.float32).pin_memory(),
+                          np.dtype(np.float64): torch.zeros((1, 2), dtype=torch.float64).pin_memory()}
+        self._act_dev = {k: torch.zeros_like(v, device=dev) for k, v in self._act_host.items()}
 
     @property
     def steps(self):
@@ -48,11 +56,19 @@ class UAVWorld2D:
 
     def step(self, action):  # UW:137
         a = np.asarray(action)
-        if a.dtype != np.float32:
-            a = a.astype(np.float64)
-        obs, rew, done, info = self._batched.step(torch.from_numpy(np.ascontiguousarray(a.reshape(1, 2))).to(self._batched.device))
-        return (obs[0].cpu().numpy().copy(), np.float32(rew[0].item()), bool(done[0].item()),
-                {"distance": np.float32(info["distance"][0].item())})
+        key = np.dtype(np.float32) if a.dtype == np.float32 else np.dtype(np.float64)  # float32 matters on step 1 (UW:142)
+        self._act_host[key].numpy()[0] = a
+        self._act_dev[key].copy_(self._act_host[key], non_blocking=True)
+        b = self._batched
+        obs, rew, done, info = b.step(self._act_dev[key])
+        p = self._pack
+        p[:16].view(torch.float32).copy_(obs[0]); p[16:20].view(torch.float32).copy_(rew)
+        p[20:24].view(torch.float32).copy_(info["distance"]); p[24:25].copy_(b._done)
+        self._host.copy_(p, non_blocking=True)
+        torch.cuda.current_stream(b.device).synchronize()
+        h = self._host_np
+        return (h[:16].view(np.float32).copy(), np.float32(h[16:20].view(np.float32)[0]), bool(h[24]),
+                {"distance": np.float32(h[20:24].view(np.float32)[0])})
 
     def render(self, mode="human"):  # UW:175 — no-op on a headless node
         return None
