@@ -1,0 +1,51 @@
+"""bench.py contract checks on the GPU box: the one-line JSON at N=1, and a 2-rank rehearsal of the N>1
+launch path (both ranks share the one GPU and talk over gloo: RCCL refuses two ranks per device; the real
+multi-GPU run is the driver's)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_line():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "300", "--warmup", "30", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 300 and d["warmup"] == 30
+    assert d["metric"] == "env-steps/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 400.0   # > 5 % of peak or something broke
+    assert d["value"] > 5e7, "target of BASELINE.json: >= 50 M env-steps/s"
+    assert abs(d["value"] - 65536 * 300 / (d["ms_per_step"] * 300 / 1e3)) / d["value"] < 1e-6
+
+
+def test_two_rank_rehearsal():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, UAVX_REHEARSAL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                          "--steps", "200", "--warmup", "20", "--envs", "8192"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["parallelism"] == "env-index shard x2"
+    assert abs(d["value"] - 2 * 8192 * 200 / (d["ms_per_step"] * 200 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
+    assert "cpu_baseline" not in d
+    assert d["episode_metrics"]["mean_steps"] == 223.0   # 3 capture-warmup + 20 warmup + 200 timed steps on every env of both shards
