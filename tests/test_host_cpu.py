@@ -152,3 +152,40 @@ def test_abi_argument_validation_without_gpu():
     assert b"null handle" in L.uavx_last_error(None)
     uw = _lib.UWConfig(100.0, 100.0, 12.0, 5.0, 0.0)
     assert L.uavx_uw_create(ctypes.byref(uw), 8, 0, 0, ctypes.byref(h)) == -1       # tau == 0
+
+
+def test_policy_checkpoint_layout_on_cpu(tmp_path):
+    """The batched actor mirrors the reference's GaussianPolicy parameter names (model.py:64-78) and loads the
+    'policy_state_dict' entry of SAC.save_checkpoint (sac.py:108) with weights_only=True."""
+    from gym_uav_collision_avoidance_amd.policy import GaussianPolicy, load_reference_checkpoint
+    torch.manual_seed(1)
+    src = GaussianPolicy()
+    assert set(src.state_dict()) == {"linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                                     "mean_linear.weight", "mean_linear.bias", "log_std_linear.weight",
+                                     "log_std_linear.bias"}
+    path = tmp_path / "weights.chpt"
+    torch.save({"policy_state_dict": src.state_dict(), "critic_state_dict": {}, "critic_target_state_dict": {},
+                "critic_optimizer_state_dict": {}, "policy_optimizer_state_dict": {}}, path)
+    pol = load_reference_checkpoint(str(path), device="cpu")
+    obs = torch.rand((7, 3, 10))
+    a = pol.act(obs)
+    assert a.shape == (7, 3, 2) and float(a.abs().max()) <= 1.0
+    assert torch.allclose(a, torch.tanh(src(obs)[0]))
+    g = torch.Generator().manual_seed(0)
+    assert not torch.equal(pol.act(obs, evaluate=False, generator=g), a)
+
+
+def test_seek_policy_output_convention():
+    """The observation-driven controller used by the evaluation tests emits policy outputs in [-1,1]^2 whose
+    polar conversion (test_sac_multi.py:77-80) points at the target."""
+    import math
+    from gym_uav_collision_avoidance_amd.evaluate import seek_policy
+    pol = seek_policy()
+    obs = torch.zeros((1, 1, 10))
+    obs[0, 0, 1] = 0.25          # heading theta_v = pi/4
+    obs[0, 0, 2] = 30.0 / math.hypot(50.0, 50.0)   # 30 m from the target
+    obs[0, 0, 3] = 0.5           # target is 90 degrees to the left of the heading
+    a = pol(obs)[0, 0]
+    v = (float(a[0]) / 2 + 0.5) * math.sqrt(200.0)
+    th = float(a[1]) * math.pi
+    assert abs(th - 0.75 * math.pi) < 1e-6 and abs(v - 8.0) < 1e-5   # capped cruise speed, bearing 135 degrees
