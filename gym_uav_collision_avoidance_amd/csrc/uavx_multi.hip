@@ -24,8 +24,10 @@
 //   prev_distance (AG:18) is NOT stored: for an agent that is not done it always equals ||target - location||
 //   (AG:33-34, MUW:155,229), so it is recomputed from the loaded position; values a caller pokes in that
 //   break this identity live in prev_ovr[A] behind the PREVD_OVR flag bit (read only when the bit is set).
-//   per-env uint32 steps[E] (r/w by the env's first lane), reach[E] / coll[E] (atomics on the rare
-//   events), episode[E] (reset only).
+//   per wave:  wave_steps[W] (one no-return atomic per launch; env.steps = wave_steps - env_rec.x)
+//   per env:   reach[E] / coll[E] (atomics on the rare events), env_rec[E] (16 B: steps base, episode index,
+//              running returns; touched by reset / step_ex only), episode statistics (fin_*).
+// One wavefront per workgroup (kBlock = 64).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -61,7 +63,7 @@ struct MultiParams {
     float inv_diag;       // 1/‖(x_size,y_size)‖            MUW:17,68
     float two_r_reset;    // float32(2R), reset rejection (MUW:135,146,151)
     int recip_ok;         // div_tau() may use the reciprocal form for this tau
-    int N, epw, magic;    // agents per env, envs per wave, ceil(65536/N)+... for lane/N
+    int N, epw, magic;    // agents per env, envs per wave, 65536/N + 1 (lane / N == (lane * magic) >> 16 for lane < 64)
     int64_t E, env_offset;
     float2 *pos;
     float *prev_ovr;

@@ -189,3 +189,10 @@ def test_seek_policy_output_convention():
     v = (float(a[0]) / 2 + 0.5) * math.sqrt(200.0)
     th = float(a[1]) * math.pi
     assert abs(th - 0.75 * math.pi) < 1e-6 and abs(v - 8.0) < 1e-5   # capped cruise speed, bearing 135 degrees
+
+
+def test_lane_to_env_multiply_shift_is_exact():
+    """lane_map() of the runtime-N step kernel divides the lane index by N with (lane * (65536//N + 1)) >> 16."""
+    for n in range(1, 65):
+        magic = 65536 // n + 1
+        assert all(((lane * magic) >> 16) == lane // n for lane in range(64)), n
