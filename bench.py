@@ -154,7 +154,9 @@ def main():
     env.reset()
 
     R = args.ring
-    if args.mode == "graph":
+    mode = args.mode
+    graph = None
+    if mode == "graph":
         # capture R consecutive steps (each reading its own action batch) into one hipGraph
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -162,11 +164,17 @@ def main():
             for i in range(3):
                 step(ring[i % R])
         torch.cuda.current_stream(device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for i in range(R):
-                step(ring[i])
-
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime during capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                for i in range(R):
+                    step(ring[i])
+        except Exception as exc:  # eager stepping is GPU-bound as well (4.3 us host cost per call): fall back
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); using --mode launch", file=sys.stderr)
+            graph, mode = None, "launch"
+            torch.cuda.synchronize(device)
+    if graph is not None:
         def run(nsteps):
             full, rem = divmod(nsteps, R)
             for _ in range(full):
@@ -221,9 +229,9 @@ def main():
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (positions/obs) + f64 (velocity)", "data": "synthetic",
             "config": {"workload": f"{E} envs x {N} UAVs per GPU ({cfg_tag}), {world_name} defaults, "
-                                   f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={args.mode}"
+                                   f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={mode}"
                                    + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else ""),
-                       "envs_per_gpu": E, "agents": N, "parallelism": f"env-index shard x{world}", "mode": args.mode},
+                       "envs_per_gpu": E, "agents": N, "parallelism": f"env-index shard x{world}", "mode": mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
