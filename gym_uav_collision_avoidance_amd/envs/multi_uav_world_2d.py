@@ -41,6 +41,11 @@ class MultiUAVWorld2D:
         self.max_acceleratoin, self.min_acceleratoin = b.max_acceleratoin, b.min_acceleratoin
         self.tau = b.tau
         self.collider_radius, self.d_sense = collider_radius, d_sense
+        self.max_window_size = 800  # MUW:25 / UW:25 (only used by the rgb_array rasteriser here)
+        if x_size > y_size:
+            self.window_size_x, self.window_size_y = self.max_window_size, self.max_window_size / x_size * y_size
+        else:
+            self.window_size_y, self.window_size_x = self.max_window_size, self.max_window_size / y_size * x_size
         self.observation_space: Box = b.observation_space
         self.action_space: Box = b.action_space
         self.agent_list = []

@@ -21,6 +21,11 @@ class UAVWorld2D:
         self.max_speed, self.min_speed = b.max_speed, b.min_speed
         self.max_acceleratoin, self.min_acceleratoin = b.max_acceleratoin, b.min_acceleratoin
         self.tau = b.tau
+        self.max_window_size = 800  # MUW:25 / UW:25 (only used by the rgb_array rasteriser here)
+        if x_size > y_size:
+            self.window_size_x, self.window_size_y = self.max_window_size, self.max_window_size / x_size * y_size
+        else:
+            self.window_size_y, self.window_size_x = self.max_window_size, self.max_window_size / y_size * x_size
         self.observation_space, self.action_space = b.observation_space, b.action_space
         self.window = None
         self.clock = None

@@ -483,3 +483,44 @@ def test_side_stream_and_hip_array_interface(amd):
     iface = amd.HipArray(oa).__hip_array_interface__
     assert iface["data"][0] == oa.data_ptr() and iface["shape"] == (E, n, 10) and iface["typestr"] == "<f4"
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomized_constructor_parameters(amd, oracle_mod, case):
+    """Random world sizes / speed and acceleration limits / collider radii / sensing ranges / agent counts,
+    including degenerate ones (collider_radius 0, d_sense below 2R, long thin boxes): device vs oracle, masks
+    and state bit-exact, observations / rewards within tolerance."""
+    rng = np.random.default_rng(9000 + case)
+    n = int(rng.choice([1, 2, 3, 4, 6, 8, 9, 13, 17, 32]))
+    kw = dict(x_size=float(rng.uniform(8, 120)), y_size=float(rng.uniform(8, 120)),
+              max_speed=float(rng.uniform(1, 25)), max_acceleration=float(rng.uniform(0.5, 12)),
+              collider_radius=float(rng.choice([0.0, 0.3, 0.5, 1.0, 1.7])),
+              d_sense=float(rng.choice([0.5, 3.0, 7.25, 15.0, 40.0])), num_agents=n)
+    if case == 3:
+        kw.update(x_size=200.0, y_size=6.0)
+    while n * 3.2 * (2 * kw["collider_radius"]) ** 2 > 0.5 * kw["x_size"] * kw["y_size"]:
+        kw["x_size"] *= 1.5; kw["y_size"] *= 1.5          # keep the rejection sampler's acceptance rate sane
+    E = 300
+    env = amd.BatchedMultiUAVWorld2D(E, seed=case, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    obs_g = env.reset()
+    orc.reset_philox(case)
+    assert obs_err(_np(obs_g), orc.observe()) <= TOL, kw
+    vmax = kw["max_speed"]
+    for t in range(40):
+        if t % 2:
+            act = rng.uniform(-vmax, vmax, size=(E, n, 2)).astype(np.float32)
+        else:
+            d = orc.tgt - orc.loc
+            act = d * rng.uniform(0.1, 2.0, size=(E, n, 1))
+        ev = bool(t % 4 == 3)
+        obs_g, rew_g, done_g, _ = env.step(act, evaluate=ev)
+        obs_o, rew_o, done_o = orc.step(act, evaluate=ev)
+        ctx = f"case {case} {kw} step {t}"
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        ref = orc.get_state()
+        _check_multi_state(env, dict(flags=ref["flags"], loc=ref["loc"], prev_d=ref["prev_d"], vel=ref["vel"],
+                                     counters=ref["counters"][:, :3]), ctx)
+        assert obs_err(_np(obs_g), obs_o) <= TOL, ctx
+        assert (np.abs(_np(rew_g) - rew_o) <= TOL * np.maximum(1.0, np.abs(rew_o))).all(), ctx
+    env.close()
