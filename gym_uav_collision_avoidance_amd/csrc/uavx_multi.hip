@@ -767,14 +767,19 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
     uint4 rec = make_uint4(0, 0, 0, 0);
     if (go) rec = p.env_rec[m.e];
     const uint32_t episode = rec.y & ~kRecEnded;
+    EpisodeFold fold = {};
+    uint32_t wc = 0;
+    if (go && m.i == 0) {  // statistics words requested before the draw, consumed after it
+        fold = fold_load(p, m.e);
+        wc = p.wave_steps[m.wave];
+    }
     reset_envs_wave<NT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
     if (go) {
         p.pos[m.a] = make_float2(s.x, s.y);
         p.vel[m.a] = make_double2(0.0, 0.0);
         p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, 0u};
         if (m.i == 0) {
-            const uint32_t wc = p.wave_steps[m.wave];
-            fold_store(p, m.e, wc - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold_load(p, m.e));
+            fold_store(p, m.e, wc - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold);
             p.env_rec[m.e] = make_uint4(wc, episode + 1u, 0u, 0u);  // MUW:166 steps = 0, new episode, no running return
         }
     }
