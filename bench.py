@@ -82,7 +82,15 @@ def cpu_baseline(n_agents, budget_s=12.0):
             if time.perf_counter() - t0 > budget_s / 2:
                 break
         out[label] = E * steps / (time.perf_counter() - t0)
-    return dict(value=out["all"], unit="env-steps/s", cores=cores, kind="port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=out["all"], unit="env-steps/s", cores=cores, kind="port", cpu_model=model, host_cpus=os.cpu_count(),
                 sample=f"{E} envs x {n_agents} UAVs, oracle/uavx_oracle.c with OpenMP over envs on {cores} threads, ~{budget_s / 2:.0f} s",
                 single_thread_value=out["1"])
 
