@@ -5,7 +5,9 @@
  *   AG  = /root/reference/gym_uav_collision_avoidance/envs/uav_agent.py
  *   UW  = /root/reference/gym_uav_collision_avoidance/envs/uav_world_2d.py
  * following the reference's op order and dtypes as evaluated by numpy 2.2.6 (NEP 50) + glibc libm.
- * It is pinned against fixtures generated from the reference itself (tests/golden/make_golden.py).
+ * PARITY PINNED: bit-exact against fixtures generated from the reference itself
+ * (tests/golden/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py) and against the live
+ * reference on fresh seeds wherever it is mounted (tests/test_reference_live.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product (gym_uav_collision_avoidance_amd) never links, imports or falls back to it.
