@@ -6,7 +6,7 @@
  *   UW  = /root/reference/gym_uav_collision_avoidance/envs/uav_world_2d.py
  * following the reference's op order and dtypes as evaluated by numpy 2.2.6 (NEP 50) + glibc libm.
  * PARITY PINNED: bit-exact against fixtures generated from the reference itself
- * (tests/golden/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py) and against the live
+ * (tests/golden/make_golden.py writes tests/golden/ npz files; tests/test_oracle_golden.py) and against the live
  * reference on fresh seeds wherever it is mounted (tests/test_reference_live.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
