@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Soak test (not part of the default suite): long closed-loop rollouts with auto-reset, device vs oracle,
+state / masks / reset streams compared bit-for-bit every step, observations and rewards every 16th step.
+
+    python tools/soak.py [steps] [envs]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402
+from golden_util import obs_err  # noqa: E402
+from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+for n, kw in ((4, {}), (8, dict(x_size=40.0, y_size=40.0)), (10, {}), (3, dict(x_size=16.0, y_size=16.0, d_sense=6.0)),
+              (24, dict(x_size=70.0, y_size=70.0))):
+    Ecur = E if n <= 10 else E // 4
+    env = BatchedMultiUAVWorld2D(Ecur, num_agents=n, seed=100 + n, **kw)
+    orc = oracle.OracleMulti(num_envs=Ecur, num_agents=n, nthreads=16, **kw)
+    env.reset(); orc.reset_philox(100 + n)
+    rng = np.random.default_rng(n)
+    t0 = time.time()
+    worst_o = worst_r = 0.0
+    resets = 0
+    for t in range(steps):
+        d = orc.tgt - orc.loc
+        dist = np.linalg.norm(d, axis=-1, keepdims=True)
+        act = d / np.maximum(dist, 1e-9) * np.where(dist > 0.3, np.minimum(8.0, np.sqrt(4.0 * dist)), 0.0)
+        noisy = rng.random((Ecur, n, 1)) < 0.15
+        act = np.where(noisy, rng.uniform(-10, 10, size=act.shape), act)
+        policy = "all_done" if (t // 500) % 2 else "agent0_done"
+        og, rg, dg, info = env.step_ex(act, evaluate=(policy == "all_done"), auto_reset=policy, step_cap=700)
+        oo, ro, do, rm = orc.step_ex(act, evaluate=(policy == "all_done"), reset_policy=1 if policy == "agent0_done" else 2,
+                                     step_cap=700, track_returns=True, seed=100 + n)
+        resets += int(rm.sum())
+        assert np.array_equal(info["reset_mask"].cpu().numpy().astype(np.uint8), rm), (n, t)
+        assert np.array_equal(dg.cpu().numpy().astype(np.uint8), do), (n, t)
+        st = env.get_state(); ref = orc.get_state()
+        for k in ("loc", "vel", "tgt", "prev_d", "flags"):
+            assert np.array_equal(st[k].cpu().numpy(), ref[k]), (n, t, k)
+        assert np.array_equal(st["counters"].cpu().numpy(), ref["counters"].astype(np.int32)), (n, t)
+        if t % 16 == 0:
+            worst_o = max(worst_o, obs_err(og.cpu().numpy(), oo))
+            worst_r = max(worst_r, float((np.abs(rg.cpu().numpy() - ro) / np.maximum(1.0, np.abs(ro))).max()))
+            assert worst_o <= 1e-5 and worst_r <= 1e-5, (n, t, worst_o, worst_r)
+    s = env.evaluation_summary()
+    print(f"N={n:2d} E={Ecur}: {steps} steps OK in {time.time() - t0:.1f} s; resets {resets}; reach {int(orc.fin_counts[:, 2].sum())} "
+          f"hard collisions {int(orc.fin_counts[:, 3].sum())}; worst obs err {worst_o:.2e} rew err {worst_r:.2e}; "
+          f"SR {s['success_rate']:.3f} CR {s['collision_rate']:.3f}", flush=True)
+    assert np.array_equal(env.episode_stats()["episodes"].cpu().numpy(), orc.fin_counts[:, 0])
+    env.close()
+print("soak passed")
