@@ -17,7 +17,7 @@ F32, F64 = 0, 1
 # every symbol include/uavx.h declares (tests check the built library exports each of them)
 SYMBOLS = (
     "uavx_version", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
-    "uavx_num_agents", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
+    "uavx_num_agents", "uavx_set_config", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
     "uavx_set_state", "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
     "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
     "uavx_uw_reset", "uavx_uw_step", "uavx_uw_observe", "uavx_uw_get_state", "uavx_uw_set_state",
@@ -98,6 +98,7 @@ def load():
     L.uavx_num_envs.argtypes = [vp]
     L.uavx_num_envs.restype = i64
     L.uavx_num_agents.argtypes = [vp]
+    L.uavx_set_config.argtypes = [vp, ctypes.POINTER(Config)]
     L.uavx_reset.argtypes = [vp, vp, u64, vp, vp]
     L.uavx_step.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     L.uavx_step_k.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp]

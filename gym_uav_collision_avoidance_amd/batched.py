@@ -114,23 +114,9 @@ class BatchedMultiUAVWorld2D(_Base):
         if not (1 <= int(num_agents) <= _lib.MAX_AGENTS):
             raise ValueError(f"uavx: num_agents must be in [1, {_lib.MAX_AGENTS}]")
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
-        self.x_size, self.y_size = float(x_size), float(y_size)
-        self.max_speed = np.array([max_speed, max_speed], dtype=np.float64)            # MUW:21
-        self.min_speed = -self.max_speed
-        self.max_acceleratoin = np.array([max_acceleration, max_acceleration], dtype=np.float64)  # sic, MUW:23
-        self.min_acceleratoin = -self.max_acceleratoin
-        self.map_diagonal_size = float(np.hypot(x_size, y_size))                         # MUW:17
-        self.min_location = np.array([-x_size / 2.0, -y_size / 2.0])
-        self.max_location = np.array([x_size / 2.0, y_size / 2.0])
         self.tau = 0.02                                                                  # MUW:26
-        self.collider_radius, self.d_sense = collider_radius, d_sense
         self.env_offset, self.seed = int(env_offset), int(seed)
-        # MUW:44-47 (low[9] = 1 is the reference's own typo; kept for space equality)
-        self.observation_space = Box(np.array([0, -1, 0, -1, 0, -1, -1, 0, -1, 1]), np.ones(10), shape=(10,),
-                                     dtype=np.float32)
-        self.action_space = Box(-max_speed, max_speed, shape=(2,), dtype=np.float32)
-        cfg = _lib.Config(x_size, y_size, max_speed, max_acceleration, collider_radius, float(d_sense), self.tau,
-                          self.num_agents, 0)
+        cfg = self._adopt_world(x_size, y_size, max_speed, max_acceleration, collider_radius, d_sense)
         _lib.check(self._L.uavx_create(ctypes.byref(cfg), self.num_envs, self.env_offset, self._dev_index,
                                        ctypes.byref(self._h)))
         E, N = self.num_envs, self.num_agents
@@ -148,6 +134,40 @@ class BatchedMultiUAVWorld2D(_Base):
         self._done_bool = self._done.view(torch.bool)
         self._step_fn = self._L.uavx_step
         self._info = {"distance": 0}
+
+    def _adopt_world(self, x_size, y_size, max_speed, max_acceleration, collider_radius, d_sense):
+        """Mirrors the scalar world parameters as the attributes MUW:13-47 exposes; returns the uavx_config."""
+        self.x_size, self.y_size = float(x_size), float(y_size)
+        self.max_speed = np.array([max_speed, max_speed], dtype=np.float64)            # MUW:21
+        self.min_speed = -self.max_speed
+        self.max_acceleratoin = np.array([max_acceleration, max_acceleration], dtype=np.float64)  # sic, MUW:23
+        self.min_acceleratoin = -self.max_acceleratoin
+        self.map_diagonal_size = float(np.hypot(x_size, y_size))                         # MUW:17
+        self.min_location = np.array([-x_size / 2.0, -y_size / 2.0])
+        self.max_location = np.array([x_size / 2.0, y_size / 2.0])
+        self.collider_radius, self.d_sense = collider_radius, d_sense
+        # MUW:44-47 (low[9] = 1 is the reference's own typo; kept for space equality)
+        self.observation_space = Box(np.array([0, -1, 0, -1, 0, -1, -1, 0, -1, 1]), np.ones(10), shape=(10,),
+                                     dtype=np.float32)
+        self.action_space = Box(-max_speed, max_speed, shape=(2,), dtype=np.float32)
+        return _lib.Config(x_size, y_size, max_speed, max_acceleration, collider_radius, float(d_sense), self.tau,
+                           self.num_agents, 0)
+
+    def set_config(self, **world):
+        """Curriculum hook: change any of x_size, y_size, max_speed, max_acceleration, collider_radius, d_sense for
+        all LATER launches (the reference re-creates the env object for this, test_sac_multi_score.py:37).  Agent
+        state is kept; a hipGraph captured before the call keeps the old parameters."""
+        cur = dict(x_size=self.x_size, y_size=self.y_size, max_speed=float(self.max_speed[0]),
+                   max_acceleration=float(self.max_acceleratoin[0]), collider_radius=self.collider_radius,
+                   d_sense=self.d_sense)
+        unknown = set(world) - set(cur)
+        if unknown:
+            raise TypeError(f"uavx: unknown world parameter(s) {sorted(unknown)}")
+        cur.update(world)
+        cfg = _lib.Config(cur["x_size"], cur["y_size"], cur["max_speed"], cur["max_acceleration"],
+                          cur["collider_radius"], float(cur["d_sense"]), self.tau, self.num_agents, 0)
+        _lib.check(self._L.uavx_set_config(self._h, ctypes.byref(cfg)), self._h)
+        self._adopt_world(**cur)
 
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self):

@@ -966,6 +966,31 @@ void launch_step_ex_nt(uavx_handle *h, dim3 grid, hipStream_t st, const StepExtr
         hipLaunchKernelGGL((step_ex_kernel<NT, false>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
 }
 
+// Everything of MultiParams that follows from the world's scalar parameters (MUW:13-58), shared by uavx_create and
+// uavx_set_config.
+void derive_world_params(const uavx_config &c, MultiParams &p) {
+    const uavx_config *cfg = &c;
+    p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
+    p.rtau = 1.0 / cfg->tau;
+    p.recip_ok = uavx_recip_division_exact(cfg->tau) ? 1 : 0;
+    p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
+    p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
+    p.speed_sq_lim = sq_threshold(0.2);
+    p.two_r_reset = (float)(2 * cfg->collider_radius);
+    p.sq_sense = sq_limit_lt((float)cfg->d_sense);
+    p.sq_two_r = sq_limit_le(p.two_r_reset);
+    p.sq_hard = sq_limit_le(1.0f);  // 2 * HARD_COLLISION_RADIUS, MUW:8,207
+    p.inv_sense = 1.0f / (float)cfg->d_sense;
+    p.vmax_norm = (float)std::sqrt(std::fma(cfg->max_speed, cfg->max_speed, cfg->max_speed * cfg->max_speed));
+    p.inv_vmax_norm = 1.0f / p.vmax_norm;
+    p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
+}
+
+bool config_valid(const uavx_config *cfg) {
+    return cfg->tau > 0 && cfg->max_speed > 0 && cfg->max_acceleration > 0 && cfg->x_size > 0 && cfg->y_size > 0 &&
+           cfg->d_sense > 0 && cfg->collider_radius >= 0;
+}
+
 dim3 wave_grid(const uavx_handle *h) {
     const int64_t waves = (h->p.E + h->p.epw - 1) / h->p.epw;
     return dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
@@ -1008,9 +1033,7 @@ const char *uavx_strerror(int status) {
 int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device, uavx_handle **out) {
     if (!cfg || !out || num_envs <= 0 || env_offset < 0) return UAVX_ERR_INVALID_ARG;
     if (cfg->num_agents < 1 || cfg->num_agents > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
-    if (!(cfg->tau > 0) || !(cfg->max_speed > 0) || !(cfg->max_acceleration > 0) || !(cfg->x_size > 0) ||
-        !(cfg->y_size > 0) || !(cfg->d_sense > 0) || !(cfg->collider_radius >= 0))
-        return UAVX_ERR_INVALID_ARG;
+    if (!config_valid(cfg)) return UAVX_ERR_INVALID_ARG;
     if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 26)) return UAVX_ERR_UNSUPPORTED;  // 32-bit byte offsets (obs: 40 B/agent)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UAVX_ERR_NO_DEVICE;
@@ -1023,20 +1046,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     MultiParams &p = h->p;
     std::memset(&p, 0, sizeof p);
     const int N = cfg->num_agents;
-    p.tau = cfg->tau; p.amax = cfg->max_acceleration; p.vmax = cfg->max_speed;
-    p.rtau = 1.0 / cfg->tau;
-    p.recip_ok = uavx_recip_division_exact(cfg->tau) ? 1 : 0;
-    p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
-    p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
-    p.speed_sq_lim = sq_threshold(0.2);
-    p.two_r_reset = (float)(2 * cfg->collider_radius);
-    p.sq_sense = sq_limit_lt((float)cfg->d_sense);
-    p.sq_two_r = sq_limit_le(p.two_r_reset);
-    p.sq_hard = sq_limit_le(1.0f);  // 2 * HARD_COLLISION_RADIUS, MUW:8,207
-    p.inv_sense = 1.0f / (float)cfg->d_sense;
-    p.vmax_norm = (float)std::sqrt(std::fma(cfg->max_speed, cfg->max_speed, cfg->max_speed * cfg->max_speed));
-    p.inv_vmax_norm = 1.0f / p.vmax_norm;
-    p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
+    derive_world_params(*cfg, p);
     p.N = N;
     p.epw = kWave / N;
     p.magic = 65536 / N + 1;
@@ -1084,6 +1094,15 @@ int uavx_destroy(uavx_handle *h) {
         (void)hipFree(h->slab);
     }
     delete h;
+    return UAVX_OK;
+}
+
+int uavx_set_config(uavx_handle *h, const uavx_config *cfg) {
+    if (!h || !cfg) return UAVX_ERR_INVALID_ARG;
+    if (cfg->num_agents != h->p.N) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_config: num_agents is fixed at creation");
+    if (!config_valid(cfg)) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_config: parameter out of range");
+    h->cfg = *cfg;
+    derive_world_params(*cfg, h->p);  // kernel arguments are taken by value at launch: later launches see the new world
     return UAVX_OK;
 }
 

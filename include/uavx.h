@@ -101,6 +101,13 @@ int uavx_destroy(uavx_handle *h);
 const char *uavx_last_error(const uavx_handle *h);
 int64_t uavx_num_envs(const uavx_handle *h);
 int uavx_num_agents(const uavx_handle *h);
+/* Curriculum hook (no reference counterpart: the reference rebuilds the env object to change the world, e.g.
+ * test_sac_multi_score.py:37 per agent count): replace the scalar world parameters of MUW:13-26 -- box size,
+ * speed / acceleration limits, collider radius, d_sense, tau -- for every LATER launch on this handle.
+ * num_agents must equal the handle's.  Agent state is untouched: agents outside a shrunken box terminate on
+ * their next step exactly as MUW:224-229 would; the observation normalisers follow the new parameters.
+ * Host-only call (no launch, no synchronisation); a hipGraph captured earlier keeps its old parameters. */
+int uavx_set_config(uavx_handle *h, const uavx_config *cfg);
 
 /* Replaces MultiUAVWorld2D.reset (MUW:116-175) for the envs with mask[e] != 0 (mask == NULL: all).
  * Start/target points are drawn by Philox4x32-10 keyed with `seed`, counter (global env, draw,

@@ -153,6 +153,8 @@ class OracleMulti:
         self.nthreads = int(nthreads)
         self.cfg = _Config(x_size, y_size, max_speed, max_acceleration, collider_radius, float(d_sense),
                            tau, num_agents, 0)
+        self._world = dict(x_size=x_size, y_size=y_size, max_speed=max_speed, max_acceleration=max_acceleration,
+                           collider_radius=collider_radius, d_sense=d_sense)
         E, N = self.E, self.N
         self.loc = np.zeros((E, N, 2), np.float64)
         self.vel = np.zeros((E, N, 2), np.float64)
@@ -182,6 +184,14 @@ class OracleMulti:
                           ("flags", flags), ("counters", counters)):
             if val is not None:
                 getattr(self, name)[...] = np.asarray(val).reshape(getattr(self, name).shape)
+
+    def set_config(self, **world):
+        """Checker side of uavx_set_config: every uavo_* call takes the config by pointer, so later calls simply see
+        the new scalar world parameters; state is untouched."""
+        self._world.update(world)
+        w = self._world
+        self.cfg = _Config(w["x_size"], w["y_size"], w["max_speed"], w["max_acceleration"], w["collider_radius"],
+                           float(w["d_sense"]), self.cfg.tau, self.N, 0)
 
     def reset_mt(self, stream, env=0, circular=False):
         lib().uavo_reset_mt(ctypes.byref(self.cfg), ctypes.byref(self._st), env,

@@ -105,6 +105,50 @@ def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, policy, code, c
     env.close()
 
 
+def test_curriculum_set_config_between_launches_vs_oracle(amd, oracle_mod):
+    """uavx_set_config: world scalars change between launches (box shrinks, sensing range / collider / speed
+    limits move); the same schedule on the oracle gives the same masks, states and reset streams."""
+    E, n = 1024, 6
+    kw = dict(x_size=40.0, y_size=30.0, num_agents=n, d_sense=12.0)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=9, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.reset()
+    orc.reset_philox(9)
+    schedule = {60: dict(x_size=24.0, y_size=24.0), 120: dict(d_sense=5.0, collider_radius=1.5),
+                180: dict(max_speed=6.0, max_acceleration=9.0), 240: dict(x_size=60.0, y_size=20.0, d_sense=20)}
+    rng = np.random.default_rng(5)
+    oob_after_shrink = 0
+    for t in range(300):
+        if t in schedule:
+            env.set_config(**schedule[t])
+            orc.set_config(**schedule[t])
+        d = orc.tgt - orc.loc
+        dist = np.linalg.norm(d, axis=-1, keepdims=True)
+        act = d / np.maximum(dist, 1e-9) * np.where(dist > 0.3, np.minimum(8.0, np.sqrt(4.0 * dist)), 0.0)
+        act = act + rng.normal(0, 0.5, size=act.shape)
+        obs_g, rew_g, done_g, info = env.step_ex(act, auto_reset="agent0_done", step_cap=80)
+        obs_o, rew_o, done_o, rmask_o = orc.step_ex(act, reset_policy=1, step_cap=80, track_returns=True, seed=9)
+        ctx = f"step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rmask_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        if t == 60:
+            oob_after_shrink = int(done_o.sum())
+        st, ref = env.get_state(), orc.get_state()
+        for key in ("loc", "vel", "tgt", "init_d", "prev_d", "flags"):
+            np.testing.assert_array_equal(_np(st[key]), ref[key], err_msg=f"{ctx} {key}")
+        assert obs_err(_np(obs_g), obs_o) <= TOL, ctx
+        assert float((np.abs(_np(rew_g) - rew_o) / np.maximum(1.0, np.abs(rew_o))).max()) <= TOL, ctx
+    assert oob_after_shrink > E, "shrinking the box must terminate the agents left outside (MUW:224-229)"
+    assert env.map_diagonal_size == pytest.approx(math.hypot(60.0, 20.0)) and env.d_sense == 20
+    assert float(env.action_space.high[0]) == 6.0
+    with pytest.raises(TypeError):
+        env.set_config(num_agents=3)
+    with pytest.raises(ValueError):
+        env.set_config(x_size=-1.0)
+    assert env.x_size == 60.0, "a refused config must leave the mirror attributes alone"
+    env.close()
+
+
 def test_step_ex_defaults_equal_plain_step(amd):
     import torch
     E, n = 3000, 4

@@ -149,6 +149,7 @@ def test_abi_argument_validation_without_gpu():
         assert L.uavx_create(ctypes.byref(good), 8, 0, 0, ctypes.byref(h)) == -3     # UAVX_ERR_NO_DEVICE
     assert L.uavx_step(None, None, 0, 0, None, None, None, None) == -1
     assert L.uavx_destroy(None) == -1
+    assert L.uavx_set_config(None, ctypes.byref(good)) == -1
     assert b"null handle" in L.uavx_last_error(None)
     uw = _lib.UWConfig(100.0, 100.0, 12.0, 5.0, 0.0)
     assert L.uavx_uw_create(ctypes.byref(uw), 8, 0, 0, ctypes.byref(h)) == -1       # tau == 0
