@@ -234,12 +234,24 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const MultiParams &p, con
     return r;
 }
 
-// Same result with N-1 -> 3 square roots, for N > 4 (the scan is O(N) per lane, and the IEEE sqrt is its
-// most expensive part): keep the THREE smallest squared distances (ties by index, like the exact scan) and
-// take roots only of those.  sqrtf is monotone, so the order by distance can differ from the order by
-// squared distance only where two roots round to the same float: {1,2} are swapped back into index order
-// if their roots tie, and if the third root ties with the second (the only way an agent outside the top
-// two could belong there) the wave falls back to the exact scan.  Bit-identical to scan_neighbours_exact.
+// Same result for N > 5 (and the N = 8 specialisation) at about half the per-neighbour cost: the scan keeps the
+// three smallest KEYS, key = (bits of the squared distance with the low 6 bits replaced by the agent index), with
+// one v_min_u32 + two v_med3_u32 per neighbour instead of a compare/select insertion of (distance, index)
+// pairs, and takes square roots only of the two winners (their exact squared distances are recomputed from LDS).
+// Non-negative floats order like their bit patterns and NaN / +inf patterns sort above every finite value, so
+// keys order by (squared distance truncated to 2^-17 relative, index).  sqrtf is monotone and two squared
+// distances whose truncations differ by two or more steps have different float32 roots, so the order by key
+// equals the reference's order by (float32 distance, index) (AG:52-62) unless two of the kept keys are within
+// one truncation step of each other at or below the sensing limit -- then (about 1 wave in 1000 on random
+// layouts; always on symmetric ones like reset(circular=True)) the wave falls back to the exact scan.  An agent
+// outside the kept three can only belong in the top two if the third key is within a step of the second, which
+// is one of the fallback conditions.  Bit-identical to scan_neighbours_exact.
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int NT, bool STEP>
 __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
                                                  float ny) {
@@ -247,24 +259,22 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
     const int N = NT ? NT : p.N;
     if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);  // <= 4 others: nothing to save
     const float4 *row = &lds.pos[m.wib][m.base];
-    float s1 = INFINITY, s2 = INFINITY, s3 = INFINITY, step_min = INFINITY;
-    int j1 = -1, j2 = -1, j3 = -1;
+    uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
+    float step_min = INFINITY;
     auto visit = [&](int j, float4 q) {
         const float dxn = q.z - nx, dyn = q.w - ny;
         const float ax = dxn * dxn, ay = dyn * dyn;
-        float sn = ax + ay;
+        const float sn = ax + ay;
         if (STEP) {
             const float dxo = q.x - nx, dyo = q.y - ny;
             const float bx = dxo * dxo, by = dyo * dyo;
             const float so = bx + by;
-            const float ss = (j < m.i) ? sn : so;
-            step_min = fminf(step_min, (ss < p.sq_sense) ? ss : INFINITY);
+            step_min = fminf(step_min, (j < m.i) ? sn : so);  // fminf drops NaN; the d_sense test follows the loop
         }
-        sn = (sn < p.sq_sense) ? sn : INFINITY;  // AG:52
-        const bool lt1 = sn < s1, lt2 = sn < s2, lt3 = sn < s3;
-        s3 = lt2 ? s2 : (lt3 ? sn : s3);  j3 = lt2 ? j2 : (lt3 ? j : j3);
-        s2 = lt1 ? s1 : (lt2 ? sn : s2);  j2 = lt1 ? j1 : (lt2 ? j : j2);
-        s1 = lt1 ? sn : s1;               j1 = lt1 ? j : j1;
+        const uint32_t key = (__float_as_uint(sn) & ~63u) | (uint32_t)j;
+        k3 = med3_u32(k2, k3, key);
+        k2 = med3_u32(k1, k2, key);
+        k1 = min(k1, key);
     };
     if (NT) {  // compile-time N: all LDS reads issued before the first use
         constexpr int M = NT > 1 ? NT - 1 : 1;
@@ -278,19 +288,35 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
 #pragma unroll
         for (int k = 0; k < NT - 1; k++) visit(js[k], q[k]);
     } else {
-#pragma unroll 2
-        for (int k = 0; k < N - 1; k++) {
+        // two neighbours per trip, written out (inline asm is convergent in HIP, which rules out the unroll pragma)
+        int k = 0;
+        for (; k + 1 < N - 1; k += 2) {
+            const int ja = k + (k >= m.i ? 1 : 0), jb = k + 1 + (k + 1 >= m.i ? 1 : 0);
+            const float4 qa = row[ja], qb = row[jb];
+            visit(ja, qa);
+            visit(jb, qb);
+        }
+        if (k < N - 1) {
             const int j = k + (k >= m.i ? 1 : 0);
             visit(j, row[j]);
         }
     }
+    // N > 5: at least five neighbours were visited, so k1..k3 are real keys (their low bits are agent indices)
+    const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(p.sq_sense) >> 6;
+    const bool near_tie = (t2 - t1 <= 1u && t1 <= ts) || (t3 - t2 <= 1u && t2 <= ts);
+    if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);
+    const int j1 = (int)(k1 & 63u), j2 = (int)(k2 & 63u);
+    const float4 q1 = row[j1], q2 = row[j2];
+    const float ex1 = q1.z - nx, ey1 = q1.w - ny, ex2 = q2.z - nx, ey2 = q2.w - ny;
+    const float mx1 = ex1 * ex1, my1 = ey1 * ey1, mx2 = ex2 * ex2, my2 = ey2 * ey2;
+    const float s1 = mx1 + my1, s2 = mx2 + my2;
+    const bool in1 = s1 < p.sq_sense, in2 = s2 < p.sq_sense;  // AG:52
     Neigh r;
-    r.step_sq_min = step_min;
-    float d1 = sqrtf(s1), d2 = sqrtf(s2);
-    const float d3 = sqrtf(s3);
-    if (__any(d3 == d2 && d2 < INFINITY)) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);
-    if (d1 == d2 && j2 < j1 && j2 >= 0) { const int t = j1; j1 = j2; j2 = t; }  // s1 < s2 whose roots tie: index order (AG:62)
-    r.d1 = d1; r.d2 = d2; r.j1 = (s1 < INFINITY) ? j1 : -1; r.j2 = (s2 < INFINITY) ? j2 : -1;
+    r.step_sq_min = (step_min < p.sq_sense) ? step_min : INFINITY;
+    r.d1 = in1 ? sqrtf(s1) : INFINITY;
+    r.d2 = in2 ? sqrtf(s2) : INFINITY;
+    r.j1 = in1 ? j1 : -1;
+    r.j2 = in2 ? j2 : -1;
     return r;
 }
 
