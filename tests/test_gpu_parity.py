@@ -370,6 +370,48 @@ def test_errors_are_loud(amd):
     env.close()
 
 
+@pytest.mark.parametrize("n", [6, 8, 13, 24])
+def test_neighbour_order_on_near_ties(amd, oracle_mod, n):
+    """The N>5 scan orders neighbours by an integer key (squared-distance bits truncated to 2^-17 relative, index
+    in the low bits) and must fall back to the exact (float32 distance, index) order whenever that truncation
+    could matter.  Rings of neighbours whose radii differ by 0 ... a few thousand float32 ulps, in shuffled index
+    order, around the sensing limit too: nearest-two identity (their heading columns differ) and every mask must
+    equal the oracle's, for observe() and for a step."""
+    E = 1500
+    kw = dict(num_agents=n, d_sense=9.0, x_size=60.0, y_size=60.0)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=3, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.reset(); orc.reset_philox(3)
+    rng = np.random.default_rng(n)
+    loc = np.zeros((E, n, 2), np.float32)
+    centre = rng.uniform(-8, 8, size=(E, 1, 2)).astype(np.float32)
+    r0 = np.where(rng.random((E, 1)) < 0.3, 9.0, rng.uniform(1.2, 8.5, size=(E, 1)))   # 30 %: ring at d_sense
+    eps = rng.choice([0.0, 0.0, 2.0 ** -23, -2.0 ** -23, 2.0 ** -21, 2.0 ** -18, -2.0 ** -17, 2.0 ** -16, 2.0 ** -12],
+                     size=(E, n - 1))
+    ang = rng.uniform(-np.pi, np.pi, size=(E, n - 1))
+    ring = (r0 * (1.0 + eps))[..., None] * np.stack([np.cos(ang), np.sin(ang)], -1)
+    far = rng.random((E, n - 1)) < 0.25                                                  # some well outside range
+    ring = np.where(far[..., None], ring * 2.5, ring)
+    who = np.argsort(rng.random((E, n)), axis=1)                                         # which agent is the centre
+    others = np.stack([np.delete(np.arange(n), who[e, 0]) for e in range(E)])
+    loc[np.arange(E), who[:, 0]] = centre[:, 0]
+    loc[np.arange(E)[:, None], others] = (centre + ring).astype(np.float32)
+    vel = rng.uniform(-3, 3, size=(E, n, 2))
+    env.set_state(loc=loc, vel=vel); orc.set_state(loc=loc, vel=vel)
+    obs_g, obs_o = _np(env.observe()), orc.observe()
+    assert obs_err(obs_g, obs_o) <= TOL
+    act = rng.uniform(-10, 10, size=(E, n, 2)).astype(np.float32)
+    og, rg, dg, _ = env.step(act)
+    oo, ro, do = orc.step(act)
+    np.testing.assert_array_equal(_np(dg).astype(np.uint8), do)
+    ref = orc.get_state()
+    _check_multi_state(env, dict(flags=ref["flags"], loc=ref["loc"], prev_d=ref["prev_d"], vel=ref["vel"],
+                                 counters=ref["counters"][:, :3]), f"near ties n={n}")
+    # the poke leaves prev_distance stale, so |reward| reaches hundreds (MUW:190): relative bar beyond |r| = 1
+    assert obs_err(_np(og), oo) <= TOL and (np.abs(_np(rg) - ro) <= TOL * np.maximum(1.0, np.abs(ro))).all()
+    env.close()
+
+
 def test_poked_state_keeps_reference_prev_distance_semantics(amd, oracle_mod):
     """prev_distance is not stored on the device (it is derived from position/target); values that break
     that identity — a caller moving an agent without touching prev_distance, as
