@@ -9,6 +9,7 @@ there is no CPU path in this package.
 from . import _lib
 from .batched import BatchedMultiUAVWorld2D, BatchedUAVWorld2D, HipArray
 from .spaces import Box
+from .vector import UAVSingleVectorEnv, UAVVectorEnv
 
 ENV_IDS = {  # gym registration ids of the reference (gym_uav_collision_avoidance/__init__.py:3-10)
     "gym_uav_collision_avoidance/UAVWorld2D-v0": "gym_uav_collision_avoidance_amd.envs:UAVWorld2D",
@@ -23,4 +24,5 @@ def make(env_id, **kwargs):
     return getattr(importlib.import_module(mod), cls)(**kwargs)
 
 
-__all__ = ["BatchedMultiUAVWorld2D", "BatchedUAVWorld2D", "HipArray", "Box", "make", "ENV_IDS"]
+__all__ = ["BatchedMultiUAVWorld2D", "BatchedUAVWorld2D", "HipArray", "Box", "UAVVectorEnv", "UAVSingleVectorEnv",
+           "make", "ENV_IDS"]

@@ -10,6 +10,17 @@ class Box:
         self.low = np.broadcast_to(np.asarray(low, dtype=self.dtype), self.shape).copy()
         self.high = np.broadcast_to(np.asarray(high, dtype=self.dtype), self.shape).copy()
 
+    @classmethod
+    def batched(cls, space, lead):
+        """gym.vector.utils.batch_space for a Box: `lead` extra leading dims.  low/high are read-only broadcast
+        views of the single space's bounds (a 1 M-env batch would otherwise carry hundreds of MB of bounds)."""
+        b = cls.__new__(cls)
+        b.dtype = space.dtype
+        b.shape = tuple(lead) + space.shape
+        b.low = np.broadcast_to(space.low, b.shape)
+        b.high = np.broadcast_to(space.high, b.shape)
+        return b
+
     def sample(self):
         return np.random.uniform(self.low, self.high, size=self.shape).astype(self.dtype)
 

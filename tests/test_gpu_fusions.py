@@ -149,6 +149,56 @@ def test_curriculum_set_config_between_launches_vs_oracle(amd, oracle_mod):
     env.close()
 
 
+def test_vector_env_surface_drives_one_launch_per_step(amd, oracle_mod):
+    """UAVVectorEnv: gym.vector.VectorEnv call surface (spaces, reset, step_async/step_wait, set_attr) over the
+    fused launch; trajectories equal the oracle's step_ex under the trainers' reset rule."""
+    import torch
+    from gym_uav_collision_avoidance_amd import UAVSingleVectorEnv, UAVVectorEnv
+    E, n = 640, 4
+    venv = UAVVectorEnv(E, num_agents=n, step_cap=50, polar=True, seed=21, x_size=30.0, y_size=30.0)
+    assert len(venv) == E and venv.is_vector_env and venv.num_envs == E
+    assert venv.single_observation_space.shape == (n, 10) and venv.observation_space.shape == (E, n, 10)
+    assert venv.single_action_space.shape == (n, 2) and venv.action_space.shape == (E, n, 2)
+    assert float(venv.action_space.high.max()) == 1.0 and venv.observation_space.dtype == np.float32
+    assert venv.get_attr("d_sense") == (15,) * E
+    orc = oracle_mod.OracleMulti(num_envs=E, num_agents=n, nthreads=8, x_size=30.0, y_size=30.0)
+    obs = venv.reset(seed=21)
+    orc.reset_philox(21)
+    assert obs.shape == (E, n, 10) and obs.is_cuda
+    rng = np.random.default_rng(2)
+    resets = 0
+    for t in range(150):
+        a = rng.uniform(-1, 1, size=(E, n, 2)).astype(np.float32)
+        a[..., 0] = np.minimum(a[..., 0], 0.2)
+        venv.step_async(torch.from_numpy(a).to(venv.device))
+        with pytest.raises(RuntimeError):
+            venv.step_async(torch.from_numpy(a).to(venv.device))
+        og, rg, dg, info = venv.step_wait()
+        oo, ro, do, rm = orc.step_ex(a, action_mode=1, reset_policy=1, step_cap=50, track_returns=True, seed=21)
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm)
+        np.testing.assert_array_equal(_np(dg).astype(np.uint8), do)
+        assert obs_err(_np(og), oo) <= TOL and float(np.abs(_np(rg) - ro).max()) <= TOL
+        resets += int(rm.sum())
+    assert resets > E
+    with pytest.raises(RuntimeError):
+        venv.step_wait()
+    venv.set_attr("d_sense", [7.0] * 3)
+    assert venv.env.d_sense == 7.0
+    with pytest.raises(ValueError):
+        venv.set_attr("d_sense", [7.0, 8.0])
+    assert venv.evaluation_summary()["episodes"] == int(orc.fin_counts[:, 0].sum())
+    venv.close(); venv.close()
+    sv = UAVSingleVectorEnv(512, seed=4, step_cap=40)
+    o = sv.reset()
+    assert o.shape == (512, 4) and sv.observation_space.shape == (512, 4) and sv.single_action_space.shape == (2,)
+    ended = 0
+    for t in range(90):
+        o, r, d, info = sv.step(torch.from_numpy(rng.uniform(-12, 12, size=(512, 2)).astype(np.float32)).to(sv.device))
+        ended += int(info["reset_mask"].sum().item())
+    assert r.shape == (512,) and d.dtype == torch.bool and ended >= 512
+    sv.close()
+
+
 def test_step_ex_defaults_equal_plain_step(amd):
     import torch
     E, n = 3000, 4
