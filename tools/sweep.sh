@@ -11,6 +11,7 @@ run --envs 65536 --agents 8
 run --envs 65536 --agents 5
 run --envs 32768 --agents 10
 run --envs 16384 --agents 24
+run --envs 65536 --agents 24 --steps 500 --warmup 50 --ring 8   # BASELINE configs[4] shape: 8 UAVs + 16 scripted bodies
 run --envs 4096 --agents 1
 run --envs 4096 --world uw
 run --envs 65536 --world uw
