@@ -128,7 +128,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # UAVX_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N>1 code path -- RCCL communicator,
+    # gather, barriers -- with a single rank, to exercise it on a one-GPU box.  Never set by the driver.
+    distributed = world > 1 or os.environ.get("UAVX_FORCE_DIST") == "1"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

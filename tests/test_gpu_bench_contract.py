@@ -49,3 +49,18 @@ def test_two_rank_rehearsal():
     assert abs(d["value"] - 2 * 8192 * 200 / (d["ms_per_step"] * 200 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
     assert "cpu_baseline" not in d
     assert d["episode_metrics"]["mean_steps"] == 223.0   # 3 capture-warmup + 20 warmup + 200 timed steps on every env of both shards
+
+
+def test_rccl_code_path_with_one_rank():
+    """The N>1 branch of bench.py on the real RCCL backend (communicator on the device, gather, barriers, hipGraph
+    capture next to the RCCL watchdog thread) with a single rank: what a one-GPU box can exercise of it."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, UAVX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "1",
+                          "--steps", "200", "--warmup", "20", "--envs", "16384", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["mode"] == "graph", (d["config"], out.stderr[-1500:])
+    assert d["episode_metrics"]["mean_steps"] == 223.0
