@@ -18,7 +18,8 @@ F32, F64 = 0, 1
 SYMBOLS = (
     "uavx_version", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
     "uavx_num_agents", "uavx_set_config", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
-    "uavx_set_state", "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
+    "uavx_set_state", "uavx_set_position_mode", "uavx_get_position_mode", "uavx_set_state_f64", "uavx_get_state_f64",
+    "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
     "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
     "uavx_uw_reset", "uavx_uw_step", "uavx_uw_observe", "uavx_uw_get_state", "uavx_uw_set_state",
     "uavx_uw_step_ex", "uavx_uw_get_episode_stats", "uavx_uw_clear_episode_stats",
@@ -42,6 +43,13 @@ class StateView(ctypes.Structure):
 
 
 UWStateView = StateView  # same field list (uavx_uw_state_view)
+
+
+class StateViewF64(ctypes.Structure):  # uavx_state_view_f64
+    _fields_ = [(n, ctypes.c_void_p) for n in ("loc", "tgt", "init_d", "prev_d")]
+
+
+POS_F32, POS_F64 = 0, 1
 
 ACTION_CARTESIAN, ACTION_POLAR = 0, 1
 RESET_NEVER, RESET_AGENT0_DONE, RESET_ALL_DONE = 0, 1, 2
@@ -105,6 +113,10 @@ def load():
     L.uavx_observe.argtypes = [vp, vp, vp]
     L.uavx_get_state.argtypes = [vp, ctypes.POINTER(StateView), vp]
     L.uavx_set_state.argtypes = [vp, ctypes.POINTER(StateView), vp]
+    L.uavx_set_position_mode.argtypes = [vp, i32, vp]
+    L.uavx_get_position_mode.argtypes = [vp]
+    L.uavx_set_state_f64.argtypes = [vp, ctypes.POINTER(StateViewF64), vp]
+    L.uavx_get_state_f64.argtypes = [vp, ctypes.POINTER(StateViewF64), vp]
     L.uavx_get_metrics.argtypes = [vp, vp, vp]
     L.uavx_step_ex.argtypes = [vp, ctypes.POINTER(StepArgs), vp]
     L.uavx_get_episode_stats.argtypes = [vp, vp, vp, vp]

@@ -203,23 +203,35 @@ class BatchedMultiUAVWorld2D(_Base):
         self._resets += 1
         return obs
 
-    def reset_circular(self, radius=20.0, target_radius=23.0):
-        """reset(circular=True) of the reference (MUW:157-163) for every env: UAV i starts at angle 2*pi*i/N
-        on a circle of `radius` and must reach the antipodal point on `target_radius`.  The reference keeps
-        these points in float64; device positions are float32 (DESIGN.md numerics)."""
+    def reset_circular(self, radius=20.0, target_radius=23.0, float64=True):
+        """reset(circular=True) of the reference (MUW:157-163) for every env: UAV i starts at angle 2*pi*i/N on a
+        circle of `radius` and must reach the antipodal point on `target_radius`.  The reference installs float64
+        arrays here, so the episode runs in float64-position mode (set_position_mode); float64=False keeps the
+        float32 fast path on float32-rounded points instead (positions then drift ~1e-4 m from the reference's
+        over a few hundred steps)."""
         import math
         E, N = self.num_envs, self.num_agents
-        th = 2 * np.arange(N) * math.pi / N
-        loc = (radius * np.stack([np.cos(th), np.sin(th)], axis=1)).astype(np.float32)
-        tgt = (target_radius * np.stack([np.cos(th + math.pi), np.sin(th + math.pi)], axis=1)).astype(np.float32)
-        d = tgt - loc
-        init_d = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+        loc = np.empty((N, 2)); tgt = np.empty((N, 2)); init_d = np.empty(N)
+        for i in range(N):                                   # python floats / libm exactly as MUW:158-162
+            theta = 2 * i * math.pi / N
+            loc[i] = 20 * np.ones(2) * np.array([math.cos(theta), math.sin(theta)]) * (radius / 20.0)
+            tgt[i] = 23 * np.ones(2) * np.array([math.cos(theta + math.pi), math.sin(theta + math.pi)]) * (target_radius / 23.0)
+            init_d[i] = np.linalg.norm(tgt[i] - loc[i])      # MUW:162
         cnt = self.metrics().cpu().numpy().astype(np.int64)
         cnt[:, :3] = 0
         cnt[:, 3] += 1
-        self.set_state(loc=np.broadcast_to(loc, (E, N, 2)), tgt=np.broadcast_to(tgt, (E, N, 2)),
-                       vel=np.zeros((E, N, 2)), init_d=np.broadcast_to(init_d, (E, N)),
-                       prev_d=np.broadcast_to(init_d, (E, N)), flags=np.zeros((E, N), np.uint8), counters=cnt)
+        if float64:
+            self.set_state(vel=np.zeros((E, N, 2)), flags=np.zeros((E, N), np.uint8), counters=cnt)
+            self.set_state_f64(loc=np.broadcast_to(loc, (E, N, 2)), tgt=np.broadcast_to(tgt, (E, N, 2)),
+                               init_d=np.broadcast_to(init_d, (E, N)), prev_d=np.broadcast_to(init_d, (E, N)))
+            return self.observe()
+        self.set_position_mode("float32")
+        loc32, tgt32 = loc.astype(np.float32), tgt.astype(np.float32)
+        d = tgt32 - loc32
+        init32 = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+        self.set_state(loc=np.broadcast_to(loc32, (E, N, 2)), tgt=np.broadcast_to(tgt32, (E, N, 2)),
+                       vel=np.zeros((E, N, 2)), init_d=np.broadcast_to(init32, (E, N)),
+                       prev_d=np.broadcast_to(init32, (E, N)), flags=np.zeros((E, N), np.uint8), counters=cnt)
         return self.observe()
 
     # -- MUW:177-241 -------------------------------------------------------------------------------
@@ -366,13 +378,52 @@ class BatchedMultiUAVWorld2D(_Base):
                 arr = np.asarray(val)
                 if name == "counters":
                     arr = arr.astype(np.int64).astype(np.int32)
-                t = torch.from_numpy(np.ascontiguousarray(arr)).to(device=self.device, dtype=dt)
+                t = torch.from_numpy(np.array(arr, order="C")).to(device=self.device, dtype=dt)
             t = t.reshape(shape).contiguous()
             keep.append(t)
             ptrs[name] = t.data_ptr()
         view = _lib.StateView(*[ptrs.get(n) for n in ("loc", "vel", "tgt", "init_d", "prev_d", "flags", "counters")])
         _lib.check(self._L.uavx_set_state(self._h, ctypes.byref(view), self._stream()), self._h)
         torch.cuda.current_stream(self.device).synchronize()  # `keep` may be freed after return
+
+    # -- float64-position episodes (reset(circular=True) / caller-assigned float64 arrays, MUW:157-163) ------------
+    @property
+    def position_mode(self):
+        """"float32" (after reset(), MUW:126) or "float64" (see set_position_mode)."""
+        return "float64" if self._L.uavx_get_position_mode(self._h) == _lib.POS_F64 else "float32"
+
+    def set_position_mode(self, mode):
+        """"float64": positions / targets / init and prev distances are held and stepped as doubles, like the
+        reference does once float64 arrays were assigned to its agents; "float32" rounds them back.  All envs of the
+        batch share the mode; reset() returns to float32."""
+        code = {"float32": _lib.POS_F32, "float64": _lib.POS_F64}[mode]
+        _lib.check(self._L.uavx_set_position_mode(self._h, code, self._stream()), self._h)
+
+    _STATE64 = (("loc", 2), ("tgt", 2), ("init_d", 0), ("prev_d", 0))
+
+    def set_state_f64(self, **fields):
+        """Overwrites any subset of loc, tgt, init_d, prev_d with float64 values (enters float64-position mode)."""
+        E, N = self.num_envs, self.num_agents
+        keep, ptrs = [], {}
+        spec = {n: ((E, N, last) if last else (E, N)) for n, last in self._STATE64}
+        for name, val in fields.items():
+            if name not in spec:
+                raise ValueError(f"uavx: unknown float64 state field {name!r}")
+            t = val if isinstance(val, torch.Tensor) else torch.from_numpy(np.array(val, dtype=np.float64, order="C"))
+            t = t.to(device=self.device, dtype=torch.float64).reshape(spec[name]).contiguous()
+            keep.append(t)
+            ptrs[name] = t.data_ptr()
+        view = _lib.StateViewF64(*[ptrs.get(n) for n, _ in self._STATE64])
+        _lib.check(self._L.uavx_set_state_f64(self._h, ctypes.byref(view), self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()  # `keep` may be freed after return
+
+    def get_state_f64(self):
+        E, N = self.num_envs, self.num_agents
+        st = {n: torch.empty((E, N, last) if last else (E, N), dtype=torch.float64, device=self.device)
+              for n, last in self._STATE64}
+        view = _lib.StateViewF64(*[st[n].data_ptr() for n, _ in self._STATE64])
+        _lib.check(self._L.uavx_get_state_f64(self._h, ctypes.byref(view), self._stream()), self._h)
+        return st
 
     def metrics(self):
         """[E, 4] int32: steps, target_reach_count, collision_count, episode index (MUW:166-168)."""

@@ -859,7 +859,8 @@ __global__ __launch_bounds__(kBlock) void get_state_kernel(MultiParams p, uavx_s
 __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_state_view v) {
     const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t A = p.E * p.N;
-    if (a < A) {
+    const bool agent_fields = v.loc || v.vel || v.tgt || v.init_d || v.prev_d || v.flags;
+    if (a < A && agent_fields) {
         float2 d = p.pos[a];
         Goal g = p.goal[a];
         const float old_prev = (g.flags & kFlagPrevOvr) ? p.prev_ovr[a] : natural_prev_d(g.flags, d.x, d.y, g.tx, g.ty);
@@ -888,6 +889,8 @@ __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_s
     }
 }
 
+#include "uavx_multi_f64.hpp"
+
 }  // namespace uavx
 
 // ------------------------------------------------------------------------------------------------
@@ -900,6 +903,11 @@ struct uavx_handle {
     MultiParams p;
     int device;
     void *slab;  // one allocation holding every state array
+    // float64-position mode (uavx_set_position_mode): arrays allocated on first use
+    bool wide = false;
+    WideState w = {};
+    WideLimits wl = {};
+    void *wide_slab = nullptr;
     std::string err;
 };
 
@@ -1012,6 +1020,16 @@ void derive_world_params(const uavx_config &c, MultiParams &p) {
     p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
 }
 
+WideLimits derive_wide_limits(const uavx_config &c) {  // the python-float comparands of the float64 episodes
+    WideLimits l;
+    l.d_sense = c.d_sense;                       // AG:52
+    l.two_r = 2 * c.collider_radius;             // MUW:203
+    l.two_hard = 2 * 0.5;                        // MUW:8,207
+    l.vmax_norm = std::sqrt(std::fma(c.max_speed, c.max_speed, c.max_speed * c.max_speed));  // MUW:62,183
+    l.diag = std::sqrt(std::fma(c.y_size, c.y_size, c.x_size * c.x_size));                   // MUW:17
+    return l;
+}
+
 bool config_valid(const uavx_config *cfg) {
     return cfg->tau > 0 && cfg->max_speed > 0 && cfg->max_acceleration > 0 && cfg->x_size > 0 && cfg->y_size > 0 &&
            cfg->d_sense > 0 && cfg->collider_radius >= 0;
@@ -1073,6 +1091,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     std::memset(&p, 0, sizeof p);
     const int N = cfg->num_agents;
     derive_world_params(*cfg, p);
+    h->wl = derive_wide_limits(*cfg);
     p.N = N;
     p.epw = kWave / N;
     p.magic = 65536 / N + 1;
@@ -1118,6 +1137,7 @@ int uavx_destroy(uavx_handle *h) {
     if (h->slab) {
         DeviceGuard guard(h->device);
         (void)hipFree(h->slab);
+        if (h->wide_slab) (void)hipFree(h->wide_slab);
     }
     delete h;
     return UAVX_OK;
@@ -1129,6 +1149,7 @@ int uavx_set_config(uavx_handle *h, const uavx_config *cfg) {
     if (!config_valid(cfg)) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_config: parameter out of range");
     h->cfg = *cfg;
     derive_world_params(*cfg, h->p);  // kernel arguments are taken by value at launch: later launches see the new world
+    h->wl = derive_wide_limits(*cfg);
     return UAVX_OK;
 }
 
@@ -1136,7 +1157,15 @@ const char *uavx_last_error(const uavx_handle *h) { return h ? h->err.c_str() : 
 int64_t uavx_num_envs(const uavx_handle *h) { return h ? h->p.E : -1; }
 int uavx_num_agents(const uavx_handle *h) { return h ? h->p.N : -1; }
 
+static dim3 env_grid(const uavx_handle *h) { return dim3((unsigned)((h->p.E + kBlock - 1) / kBlock)); }
+static dim3 agent_grid(const uavx_handle *h) { return dim3((unsigned)((h->p.E * h->p.N + kBlock - 1) / kBlock)); }
+
 static int launch_observe(uavx_handle *h, float *obs, hipStream_t st) {
+    if (h->wide) {
+        hipLaunchKernelGGL(observe64_kernel, env_grid(h), dim3(kBlock), 0, st, h->p, h->w, h->wl, obs);
+        UAVX_HIP(h, hipGetLastError());
+        return UAVX_OK;
+    }
     const dim3 grid = wave_grid(h);
     switch (h->p.N) {
         case 1: hipLaunchKernelGGL((observe_kernel<1>), grid, dim3(kBlock), 0, st, h->p, obs); break;
@@ -1162,6 +1191,9 @@ int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, v
     UAVX_ENTER(h);
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 15u))
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_reset: obs not 16-byte aligned");
+    if (h->wide && mask)
+        return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_reset: a masked reset would mix float32 and float64 episodes in one handle");
+    h->wide = false;  // MUW:126,131,144: reset() installs float32 arrays again
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
     switch (h->p.N) {
@@ -1176,6 +1208,18 @@ int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, v
     return UAVX_OK;
 }
 
+static int launch_step64(uavx_handle *h, const void *actions, int action_dtype, int action_mode, int track_returns,
+                         int evaluate, float *obs, float *rew, uint8_t *done, hipStream_t st) {
+    if (action_dtype == UAVX_F64)
+        hipLaunchKernelGGL((step64_kernel<true>), env_grid(h), dim3(kBlock), 0, st, h->p, h->w, h->wl, actions, action_mode,
+                           track_returns, evaluate, obs, rew, done);
+    else
+        hipLaunchKernelGGL((step64_kernel<false>), env_grid(h), dim3(kBlock), 0, st, h->p, h->w, h->wl, actions, action_mode,
+                           track_returns, evaluate, obs, rew, done);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
 int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, int evaluate, int tape_out, float *obs,
                 float *rew, uint8_t *done, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;
@@ -1187,6 +1231,11 @@ int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, in
         (reinterpret_cast<uintptr_t>(rew) & 3u))
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: obs/actions must be 16-byte aligned, rew 4-byte aligned");
     UAVX_ENTER(h);
+    if (h->wide) {
+        if (k != 1) return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_k: k > 1 is not available for float64-position episodes");
+        return launch_step64(h, actions, action_dtype, UAVX_ACTION_CARTESIAN, 0, evaluate, obs, rew, done,
+                             static_cast<hipStream_t>(stream));
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
     switch (h->p.N) {
@@ -1218,6 +1267,13 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
         (reinterpret_cast<uintptr_t>(a->rew) & 3u))
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: obs/actions must be 16-byte aligned, rew 4-byte aligned");
     UAVX_ENTER(h);
+    if (h->wide) {
+        if (a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0)
+            return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_ex: no auto-reset / step cap for float64-position episodes");
+        if (a->reset_mask) UAVX_HIP(h, hipMemsetAsync(a->reset_mask, 0, (size_t)h->p.E, static_cast<hipStream_t>(stream)));
+        return launch_step64(h, a->actions, a->action_dtype, a->action_mode, a->track_returns, a->evaluate, a->obs, a->rew,
+                             a->done, static_cast<hipStream_t>(stream));
+    }
     StepExtra x;
     x.action_mode = a->action_mode; x.reset_policy = a->reset_policy; x.track_returns = a->track_returns;
     x.step_cap = a->step_cap; x.seed_lo = (uint32_t)a->seed; x.seed_hi = (uint32_t)(a->seed >> 32);
@@ -1264,12 +1320,25 @@ int uavx_clear_episode_stats(uavx_handle *h, void *stream) {
     return UAVX_OK;
 }
 
+static int wide_exchange(uavx_handle *h, const uavx_state_view &v, const uavx_state_view_f64 &v64, int set, hipStream_t st) {
+    hipLaunchKernelGGL(wide_exchange_kernel, agent_grid(h), dim3(kBlock), 0, st, h->p, h->w, v, v64, set);
+    UAVX_HIP(h, hipGetLastError());
+    if (v.counters) {  // env counters live in the shared arrays: the float32-mode kernels handle them
+        uavx_state_view c;
+        std::memset(&c, 0, sizeof c);
+        c.counters = v.counters;
+        if (set) hipLaunchKernelGGL(set_state_kernel, agent_grid(h), dim3(kBlock), 0, st, h->p, c);
+        else hipLaunchKernelGGL(get_state_kernel, agent_grid(h), dim3(kBlock), 0, st, h->p, c);
+        UAVX_HIP(h, hipGetLastError());
+    }
+    return UAVX_OK;
+}
+
 int uavx_get_state(uavx_handle *h, const uavx_state_view *dst, void *stream) {
     if (!h || !dst) return UAVX_ERR_INVALID_ARG;
     UAVX_ENTER(h);
-    const int64_t A = h->p.E * h->p.N;
-    hipLaunchKernelGGL(get_state_kernel, dim3((unsigned)((A + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), h->p, *dst);
+    if (h->wide) return wide_exchange(h, *dst, uavx_state_view_f64{}, 0, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(get_state_kernel, agent_grid(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->p, *dst);
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }
@@ -1277,11 +1346,61 @@ int uavx_get_state(uavx_handle *h, const uavx_state_view *dst, void *stream) {
 int uavx_set_state(uavx_handle *h, const uavx_state_view *src, void *stream) {
     if (!h || !src) return UAVX_ERR_INVALID_ARG;
     UAVX_ENTER(h);
-    const int64_t A = h->p.E * h->p.N;
-    hipLaunchKernelGGL(set_state_kernel, dim3((unsigned)((A + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), h->p, *src);
+    if (h->wide) return wide_exchange(h, *src, uavx_state_view_f64{}, 1, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(set_state_kernel, agent_grid(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->p, *src);
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
+}
+
+int uavx_get_position_mode(const uavx_handle *h) { return h ? (h->wide ? UAVX_POS_F64 : UAVX_POS_F32) : UAVX_ERR_INVALID_ARG; }
+
+int uavx_set_position_mode(uavx_handle *h, int mode, void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    if (mode != UAVX_POS_F32 && mode != UAVX_POS_F64) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_position_mode: unknown mode");
+    UAVX_ENTER(h);
+    if ((mode == UAVX_POS_F64) == h->wide) return UAVX_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == UAVX_POS_F64) {
+        if (!h->wide_slab) {  // 48 B per agent, once per handle
+            const size_t A = (size_t)h->p.E * h->p.N;
+            const size_t o_tgt = align_up(A * sizeof(double2), 256), o_init = o_tgt + align_up(A * sizeof(double2), 256);
+            const size_t o_prev = o_init + align_up(A * sizeof(double), 256), total = o_prev + align_up(A * sizeof(double), 256);
+            if (hipMalloc(&h->wide_slab, total) != hipSuccess) {
+                h->wide_slab = nullptr;
+                return fail(h, UAVX_ERR_ALLOC, "uavx_set_position_mode: hipMalloc of the float64 arrays failed");
+            }
+            char *b = static_cast<char *>(h->wide_slab);
+            h->w.pos = reinterpret_cast<double2 *>(b);
+            h->w.tgt = reinterpret_cast<double2 *>(b + o_tgt);
+            h->w.init_d = reinterpret_cast<double *>(b + o_init);
+            h->w.prev_d = reinterpret_cast<double *>(b + o_prev);
+        }
+        hipLaunchKernelGGL(widen_state_kernel, agent_grid(h), dim3(kBlock), 0, st, h->p, h->w);
+    } else {
+        hipLaunchKernelGGL(narrow_state_kernel, agent_grid(h), dim3(kBlock), 0, st, h->p, h->w);
+    }
+    UAVX_HIP(h, hipGetLastError());
+    h->wide = (mode == UAVX_POS_F64);
+    return UAVX_OK;
+}
+
+int uavx_set_state_f64(uavx_handle *h, const uavx_state_view_f64 *src, void *stream) {
+    if (!h || !src) return UAVX_ERR_INVALID_ARG;
+    const int rc = uavx_set_position_mode(h, UAVX_POS_F64, stream);  // assigning float64 arrays makes the episode float64
+    if (rc != UAVX_OK) return rc;
+    UAVX_ENTER(h);
+    uavx_state_view none;
+    std::memset(&none, 0, sizeof none);
+    return wide_exchange(h, none, *src, 1, static_cast<hipStream_t>(stream));
+}
+
+int uavx_get_state_f64(uavx_handle *h, const uavx_state_view_f64 *dst, void *stream) {
+    if (!h || !dst) return UAVX_ERR_INVALID_ARG;
+    if (!h->wide) return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_get_state_f64: the handle is in float32-position mode");
+    UAVX_ENTER(h);
+    uavx_state_view none;
+    std::memset(&none, 0, sizeof none);
+    return wide_exchange(h, none, *dst, 0, static_cast<hipStream_t>(stream));
 }
 
 int uavx_get_metrics(uavx_handle *h, uint32_t *counters, void *stream) {

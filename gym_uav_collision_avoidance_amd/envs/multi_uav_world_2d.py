@@ -113,10 +113,11 @@ class MultiUAVWorld2D:
         n = self.num_agents
         loc, tgt = self._draw_layout()
         if circular:
-            # MUW:157-163 places float64 points; device positions are float32 (numerics)
-            th = 2 * np.arange(n) * math.pi / n
-            loc = (20 * np.stack([np.cos(th), np.sin(th)], axis=1)).astype(np.float32)
-            tgt = (23 * np.stack([np.cos(th + math.pi), np.sin(th + math.pi)], axis=1)).astype(np.float32)
+            # MUW:157-163 installs float64 arrays: the episode runs in the float64-position mode of the library
+            return_obs = self._batched.reset_circular()
+            obs = self._obs_list(return_obs)
+            return (obs, self._get_info()) if return_info else obs
+        self._batched.set_position_mode("float32")                                   # MUW:126: float32 arrays again
         d = tgt - loc
         init_d = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)  # MUW:154
         self._batched.set_state(loc=loc[None], tgt=tgt[None], vel=np.zeros((1, n, 2)), init_d=init_d[None],

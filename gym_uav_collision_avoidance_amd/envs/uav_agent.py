@@ -17,13 +17,29 @@ class UAVAgentView:
         self.max_acceleration = np.array([max_acceleration, max_acceleration])  # AG:11
         self.tau = tau                                                      # AG:12
 
+    _WIDE = {"loc": "loc", "tgt": "tgt", "init_d": "init_d", "prev_d": "prev_d"}   # fields with a float64 twin
+
     def _get(self, name):
-        return self._w._batched.get_state()[name][0, self._i].cpu().numpy()
+        b = self._w._batched
+        if name in self._WIDE and b.position_mode == "float64":   # the reference would hand back its float64 array
+            return b.get_state_f64()[name][0, self._i].cpu().numpy()
+        return b.get_state()[name][0, self._i].cpu().numpy()
 
     def _set(self, name, value):
-        st = self._w._batched.get_state()[name]
-        st[0, self._i] = st.new_tensor(np.asarray(value, dtype=np.float64))
-        self._w._batched.set_state(**{name: st})
+        b = self._w._batched
+        arr = np.asarray(value)
+        # Assigning a float64 array (or python floats) to a position field makes the reference compute that episode
+        # in float64 (test_sac_multi_plot_trajectory.py:43-49); the device mode is per world, so the whole env
+        # switches (the scripts that do this assign every agent).
+        if name in self._WIDE and (b.position_mode == "float64" or (name in ("loc", "tgt") and arr.dtype == np.float64)):
+            b.set_position_mode("float64")
+            st = b.get_state_f64()[name]
+            st[0, self._i] = st.new_tensor(np.asarray(arr, dtype=np.float64))
+            b.set_state_f64(**{name: st})
+            return
+        st = b.get_state()[name]
+        st[0, self._i] = st.new_tensor(np.asarray(arr, dtype=np.float64))
+        b.set_state(**{name: st})
 
     location = property(lambda s: s._get("loc"), lambda s, v: s._set("loc", v))                 # AG:13
     velocity = property(lambda s: s._get("vel"), lambda s, v: s._set("vel", v))                 # AG:14

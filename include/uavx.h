@@ -72,6 +72,16 @@ typedef struct {
     uint32_t *counters; /* [E*4]   steps, target_reach_count, collision_count, episode index */
 } uavx_state_view;
 
+/* float64-position episodes (see uavx_set_position_mode): the same fields as Python floats / float64 arrays. */
+typedef struct {
+    double *loc;     /* [E*N*2] */
+    double *tgt;     /* [E*N*2] */
+    double *init_d;  /* [E*N]   */
+    double *prev_d;  /* [E*N]   */
+} uavx_state_view_f64;
+
+typedef enum { UAVX_POS_F32 = 0, UAVX_POS_F64 = 1 } uavx_position_mode;
+
 typedef struct {
     float *loc;        /* [E*2] UW:121 */
     double *vel;       /* [E*2] UW:122 */
@@ -183,6 +193,26 @@ int uavx_observe(uavx_handle *h, float *obs, void *stream);
  * env.agent_list[i].location etc. directly, test_sac_multi_plot_trajectory.py:43-49). */
 int uavx_get_state(uavx_handle *h, const uavx_state_view *dst, void *stream);
 int uavx_set_state(uavx_handle *h, const uavx_state_view *src, void *stream);
+
+/* Position dtype of the running episodes.  After reset() the reference's agent.location / target_location are
+ * float32 arrays (MUW:126,131,144) -- UAVX_POS_F32, the default and the fast path.  reset(circular=True)
+ * (MUW:157-163) and callers that assign their own arrays (test_sac_multi_plot_trajectory.py:43-49) install
+ * float64 arrays instead, and every position expression of that episode is then float64 (AG:29,33,51; MUW:190-
+ * 194,203,207,218).  UAVX_POS_F64 restates that episode type for ALL envs of the handle: positions, targets,
+ * init / prev distances are held as doubles and stepped by a one-thread-per-env kernel (evaluation / plotting
+ * scenario, not tuned); masks, positions, velocities and counters stay bit-exact against the reference.
+ *   uavx_set_position_mode  converts the stored state (F32->F64 exact; F64->F32 rounds) and selects the
+ *                           arithmetic of later uavx_step / uavx_step_ex / uavx_observe calls.  The first switch
+ *                           to F64 allocates 48 B per agent (the only allocation after uavx_create).
+ *   uavx_set_state_f64      overwrites any subset of the float64 fields; enters F64 mode if needed.
+ *   uavx_get_state_f64      F64 mode only (UAVX_ERR_UNSUPPORTED otherwise).
+ * In F64 mode uavx_get_state / uavx_set_state exchange rounded / widened float32 views; uavx_reset(mask=NULL)
+ * returns the handle to F32 like the reference's reset(); uavx_reset with a mask, uavx_step_k with k > 1 and
+ * uavx_step_ex with an auto-reset policy or step cap return UAVX_ERR_UNSUPPORTED. */
+int uavx_set_position_mode(uavx_handle *h, int mode, void *stream);
+int uavx_get_position_mode(const uavx_handle *h);
+int uavx_set_state_f64(uavx_handle *h, const uavx_state_view_f64 *src, void *stream);
+int uavx_get_state_f64(uavx_handle *h, const uavx_state_view_f64 *dst, void *stream);
 
 /* Episode metrics of MUW:166-168,209,221,238 as the trainers read them before reset
  * (test_sac_multi.py:164-165): counters [E*4] uint32 = steps, target_reach_count,

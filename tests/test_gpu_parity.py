@@ -75,8 +75,9 @@ def test_multi_fixture_replay(amd, name):
 
 @pytest.mark.parametrize("name", [n for n in MULTI if "circular" in n])
 def test_multi_circular_fixture_float32_positions(amd, name):
-    """reset(circular=True) makes the reference hold float64 positions (MUW:157-163); the device keeps
-    float32, so positions are compared to float32 resolution and masks must still agree."""
+    """The float32 fast path fed with the circular layout (reset_circular(float64=False)): the reference holds
+    float64 positions in this scenario (MUW:157-163), so positions are compared to float32 resolution and masks
+    within a step.  The exact counterpart is test_multi_circular_fixture_float64_mode_exact below."""
     data, meta = load_fixture(name)
     cfg = meta["cfg"]
     env = amd.BatchedMultiUAVWorld2D(1, **_ctor(cfg))
@@ -96,6 +97,124 @@ def test_multi_circular_fixture_float32_positions(amd, name):
         assert obs_err(got[:, :4], want[:, :4], angle_cols=(1, 3)) < 1e-4, f"{name} step {t}"
     assert mism <= 2, f"{name}: {mism} done-mask mismatches (success fires within a step of the reference)"
     np.testing.assert_array_equal(_np(env.metrics())[0, 1], data["counters"][-1][1])
+    env.close()
+
+
+@pytest.mark.parametrize("name", [n for n in MULTI if "circular" in n])
+def test_multi_circular_fixture_float64_mode_exact(amd, name):
+    """The same recorded circular episodes in the library's float64-position mode (uavx_set_position_mode): done
+    masks, float64 positions / prev distances, velocities, flags and counters bit for bit with the reference."""
+    data, meta = load_fixture(name)
+    cfg = meta["cfg"]
+    env = amd.BatchedMultiUAVWorld2D(1, **_ctor(cfg))
+    env.set_state(vel=data["init_vel"][None], flags=data["init_flags"][None],
+                  counters=np.concatenate([data["init_counters"], [0]])[None])
+    env.set_state_f64(loc=data["init_loc"][None], tgt=data["init_tgt"][None], init_d=data["init_init_d"][None],
+                      prev_d=data["init_prev_d"][None])
+    assert env.position_mode == "float64"
+    worst_obs = worst_rew = 0.0
+    for t in range(data["actions"].shape[0]):
+        obs, rew, done, _ = env.step(data["actions"][t][None], evaluate=bool(data["evaluate"][t]))
+        ctx = f"{name} step {t}"
+        np.testing.assert_array_equal(_np(done)[0].astype(np.uint8), data["done"][t], err_msg=ctx + " done")
+        st, st64 = env.get_state(), env.get_state_f64()
+        np.testing.assert_array_equal(_np(st64["loc"])[0], data["loc"][t], err_msg=ctx + " loc")
+        np.testing.assert_array_equal(_np(st64["prev_d"])[0], data["prev_d"][t], err_msg=ctx + " prev_d")
+        np.testing.assert_array_equal(_np(st["vel"])[0], data["vel"][t], err_msg=ctx + " vel")
+        np.testing.assert_array_equal(_np(st["flags"])[0], data["flags"][t], err_msg=ctx + " flags")
+        np.testing.assert_array_equal(_np(st["counters"])[0, :3], data["counters"][t], err_msg=ctx + " counters")
+        np.testing.assert_array_equal(_np(st["loc"])[0], data["loc"][t].astype(np.float32))   # float32 view = rounded
+        got, want = _np(obs)[0].astype(np.float64), data["obs"][t].copy()
+        ties = tie_agents(data["loc"][t], cfg["d_sense"], True)   # exact float64 ties: argsort order is platform dependent
+        got[ties, 4:] = 0
+        want[ties, 4:] = 0
+        worst_obs = max(worst_obs, obs_err(got, want))
+        worst_rew = max(worst_rew, float(np.abs(_np(rew)[0] - data["rew"][t]).max()))
+        assert worst_obs <= TOL and worst_rew <= TOL, f"{ctx}: obs err {worst_obs:.3g} rew err {worst_rew:.3g}"
+    env.close()
+
+
+@pytest.mark.parametrize("n,E", [(3, 400), (7, 150), (24, 40)])
+def test_float64_position_mode_vs_oracle_and_back(amd, oracle_mod, n, E):
+    """Random batches: reset (float32) -> a few float32 steps -> float64 mode (exact widening) -> float64 steps incl.
+    polar actions and episode-return tracking -> back to float32 (rounding, prev_distance override) -> float32 steps,
+    the oracle following the same schedule through its per-env f64pos flag."""
+    kw = dict(x_size=30.0, y_size=24.0, num_agents=n, d_sense=9.0)
+    if n >= 24:
+        kw.update(x_size=60.0, y_size=60.0)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=77, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.reset(); orc.reset_philox(77)
+    rng = np.random.default_rng(n)
+
+    def seek():
+        d = orc.tgt - orc.loc
+        act = d * rng.uniform(0.3, 2.0, size=(E, n, 1)) + rng.normal(0, 0.4, size=d.shape)
+        wild = rng.random((E, n, 1)) < 0.1
+        return np.where(wild, rng.uniform(-10, 10, size=d.shape), act)
+
+    def compare(obs_g, rew_g, done_g, obs_o, rew_o, done_o, ctx, wide):
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        st = env.get_state()
+        np.testing.assert_array_equal(_np(st["vel"]), orc.vel, err_msg=ctx + " vel")
+        np.testing.assert_array_equal(_np(st["flags"]), orc.flags, err_msg=ctx + " flags")
+        np.testing.assert_array_equal(_np(st["counters"])[:, :3], orc.counters[:, :3].astype(np.int32), err_msg=ctx)
+        if wide:
+            s64 = env.get_state_f64()
+            for k in ("loc", "tgt", "init_d", "prev_d"):
+                np.testing.assert_array_equal(_np(s64[k]), getattr(orc, k), err_msg=f"{ctx} {k}")
+        else:
+            for k in ("loc", "tgt", "init_d", "prev_d"):
+                np.testing.assert_array_equal(_np(st[k]), getattr(orc, k).astype(np.float32), err_msg=f"{ctx} {k}")
+        assert obs_err(_np(obs_g), obs_o) <= TOL, ctx
+        assert (np.abs(_np(rew_g) - rew_o) <= TOL * np.maximum(1.0, np.abs(rew_o))).all(), ctx
+
+    for t in range(15):
+        a = seek()
+        compare(*env.step(a)[:3], *orc.step(a), f"f32 warm-up {t}", False)
+    env.set_position_mode("float64")
+    orc.f64pos[:] = 1
+    assert env.position_mode == "float64"
+    assert obs_err(_np(env.observe()), orc.observe()) <= TOL
+    for t in range(120):
+        if t % 2:
+            a = rng.uniform(-1, 1, size=(E, n, 2)).astype(np.float32)
+            og, rg, dg, info = env.step_ex(a, polar=True, evaluate=bool(t % 3 == 0), track_returns=True)
+            assert not bool(info["reset_mask"].any())
+            oo, ro, do, _ = orc.step_ex(a, action_mode=1, evaluate=bool(t % 3 == 0), track_returns=True)
+        else:
+            a = seek()
+            og, rg, dg, _ = env.step(a, evaluate=bool(t % 3 == 0))
+            oo, ro, do = orc.step(a, evaluate=bool(t % 3 == 0))
+        compare(og, rg, dg, oo, ro, do, f"f64 step {t}", True)
+    assert int(orc.counters[:, 1].sum()) > 0 and int(orc.counters[:, 2].sum()) > 0, "scenario too tame"
+    # what float64 mode refuses
+    with pytest.raises(RuntimeError):
+        env.reset(mask=np.arange(E) % 2 == 0)
+    with pytest.raises(RuntimeError):
+        env.step_ex(seek(), auto_reset="agent0_done")
+    with pytest.raises(RuntimeError):
+        env.step_k(np.stack([seek()] * 4))
+    # back to float32: values round, prev_distance keeps its (rounded) value through the override slot
+    env.set_position_mode("float32")
+    assert env.position_mode == "float32"
+    orc.f64pos[:] = 0
+    for k in ("loc", "tgt", "init_d", "prev_d"):
+        getattr(orc, k)[...] = getattr(orc, k).astype(np.float32)
+    for t in range(25):
+        a = seek()
+        compare(*env.step(a)[:3], *orc.step(a), f"f32 again {t}", False)
+    # reset() always returns to float32 arrays (MUW:126)
+    env.set_position_mode("float64")
+    env.reset(); orc.reset_philox(77)
+    assert env.position_mode == "float32"
+    stats = env.episode_stats()   # the explicit reset folded the episode, returns tracked by the float64 step_ex calls
+    np.testing.assert_array_equal(_np(stats["episodes"]), orc.fin_counts[:, 0])
+    np.testing.assert_array_equal(_np(stats["steps"]), orc.fin_counts[:, 1])
+    np.testing.assert_allclose(_np(stats["return0"]), orc.fin_returns[:, 0], atol=2e-3, rtol=1e-5)
+    np.testing.assert_allclose(_np(stats["score"]), orc.fin_returns[:, 1], atol=2e-3, rtol=1e-5)
+    a = seek()
+    compare(*env.step(a)[:3], *orc.step(a), "after reset", False)
     env.close()
 
 
@@ -334,6 +453,61 @@ def test_facade_run_multi_call_pattern(amd):
     a0 = env.agent_list[0]
     a0.location = np.array([1.5, -2.5])
     assert np.allclose(a0.location, [1.5, -2.5]) and a0.done in (True, False)
+    env.close()
+
+
+def test_facade_circular_reset_and_float64_pokes(amd, oracle_mod):
+    """reset(circular=True) through the drop-in class reproduces the reference's float64 episode exactly
+    (MUW:157-163), and assigning float64 arrays to agent_list[i].location / target_location the way
+    test_sac_multi_plot_trajectory.py:43-49 does turns a random episode into a float64 one as well."""
+    import math
+    from gym_uav_collision_avoidance_amd.envs import MultiUAVWorld2D
+    data, _ = load_fixture("crafted_circular_n4")
+    n = 4
+    env = MultiUAVWorld2D(num_agents=n)
+    np.random.seed(5)
+    obs = env.reset(circular=True)
+    assert env._batched.position_mode == "float64" and obs_err(np.array(obs), data["init_obs"]) <= TOL \
+        if "init_obs" in data else env._batched.position_mode == "float64"
+    for i in range(n):
+        a = env.agent_list[i]
+        assert a.location.dtype == np.float64 and a.target_location.dtype == np.float64
+        np.testing.assert_array_equal(a.location, data["init_loc"][i])
+        np.testing.assert_array_equal(a.target_location, data["init_tgt"][i])
+        assert a.init_distance == data["init_init_d"][i] and a.prev_distance == data["init_prev_d"][i]
+    for t in range(250):
+        o, r, d, _ = env.step([data["actions"][t][i] for i in range(n)])
+        assert [bool(x) for x in d] == [bool(x) for x in data["done"][t]], t
+        assert float(np.abs(np.array(r) - data["rew"][t]).max()) <= TOL
+    for i in range(n):
+        np.testing.assert_array_equal(env.agent_list[i].location, data["loc"][249][i])
+    assert env.target_reach_count == int(data["counters"][249][1])
+    # a plain reset() installs float32 arrays again; then the plotting script's pokes
+    np.random.seed(9)
+    env.reset()
+    assert env._batched.position_mode == "float32" and env.agent_list[0].location.dtype == np.float32
+    offset = 0.5
+    for i in range(n):
+        theta = 2 * i * math.pi / n
+        env.agent_list[i].location = 20 * np.ones(2) * np.array([math.cos(theta), math.sin(theta)])
+        env.agent_list[i].target_location = 23 * np.ones(2) * np.array([math.cos(theta + math.pi - offset * math.pi / n),
+                                                                      math.sin(theta + math.pi - offset * math.pi / n)])
+    assert env._batched.position_mode == "float64"
+    orc = oracle_mod.OracleMulti(num_envs=1, num_agents=n, nthreads=1)
+    s32, s64 = env._batched.get_state(), env._batched.get_state_f64()
+    orc.set_state(loc=_np(s64["loc"]), tgt=_np(s64["tgt"]), init_d=_np(s64["init_d"]), prev_d=_np(s64["prev_d"]),
+                  vel=_np(s32["vel"]), flags=_np(s32["flags"]))
+    orc.f64pos[:] = 1
+    assert orc.loc[0, 1, 0] == 20 * math.cos(2 * math.pi / n)             # the poked python floats arrived unrounded
+    assert float(orc.init_d[0, 0]) == float(np.float32(orc.init_d[0, 0]))  # init / prev distance stay the stale float32 ones
+    for t in range(300):
+        dvec = orc.tgt[0] - orc.loc[0]
+        act = [dvec[i] * 0.8 for i in range(n)]
+        o, r, d, _ = env.step(act)
+        oo, ro, do = orc.step(np.array(act)[None])
+        assert [bool(x) for x in d] == [bool(x) for x in do[0]], t
+        assert obs_err(np.array(o), oo[0]) <= TOL and float(np.abs(np.array(r) - ro[0]).max()) <= TOL * max(1.0, float(np.abs(ro).max()))
+    np.testing.assert_array_equal(_np(env._batched.get_state_f64()["loc"]), orc.loc)
     env.close()
 
 

@@ -150,6 +150,8 @@ def test_abi_argument_validation_without_gpu():
     assert L.uavx_step(None, None, 0, 0, None, None, None, None) == -1
     assert L.uavx_destroy(None) == -1
     assert L.uavx_set_config(None, ctypes.byref(good)) == -1
+    assert L.uavx_set_position_mode(None, 1, None) == -1 and L.uavx_get_position_mode(None) == -1
+    assert L.uavx_set_state_f64(None, None, None) == -1 and L.uavx_get_state_f64(None, None, None) == -1
     assert b"null handle" in L.uavx_last_error(None)
     uw = _lib.UWConfig(100.0, 100.0, 12.0, 5.0, 0.0)
     assert L.uavx_uw_create(ctypes.byref(uw), 8, 0, 0, ctypes.byref(h)) == -1       # tau == 0
