@@ -96,3 +96,58 @@ def test_committed_fixture_regenerates_identically():
         obs, rew, done, _ = env.step(acts)
         np.testing.assert_array_equal(np.array(obs), data["obs"][t])
         np.testing.assert_array_equal(np.array([float(r) for r in rew]), data["rew"][t])
+
+
+@pytest.mark.parametrize("n,circular", [(4, True), (6, True), (5, False), (3, False)])
+def test_oracle_float64_episodes_equal_live_reference(oracle_mod, n, circular):
+    """Float64-position episodes of the live reference: reset(circular=True) (MUW:157-163), and a random reset
+    followed by the plotting script's float64 pokes of location / target_location
+    (test_sac_multi_plot_trajectory.py:43-49; init / prev distance stay the stale float32 scalars).  State and masks
+    bit for bit; in the poke pattern the reward may differ in the last float32 digit (NEP 50 evaluates
+    1.5*np.float32(init_distance) in float32 there; the oracle keeps no scalar dtypes)."""
+    MUW, _, _ = ref_loader.load()
+    np.random.seed(300 + n)
+    env = MUW(num_agents=n)
+    orc = oracle_mod.OracleMulti(num_envs=1, num_agents=n)
+    g = oracle_mod.MTStream(300 + n)
+    obs_ref = env.reset(circular=circular)
+    orc.reset_mt(g, circular=circular)
+    if not circular:
+        for i in range(n):
+            theta = 2 * i * math.pi / n
+            env.agent_list[i].location = 20 * np.ones(2) * np.array([math.cos(theta), math.sin(theta)])
+            env.agent_list[i].target_location = 23 * np.ones(2) * np.array([math.cos(theta + math.pi - 0.5 * math.pi / n),
+                                                                          math.sin(theta + math.pi - 0.5 * math.pi / n)])
+            orc.loc[0, i] = env.agent_list[i].location
+            orc.tgt[0, i] = env.agent_list[i].target_location
+        orc.f64pos[:] = 1
+    else:
+        np.testing.assert_array_equal(orc.observe()[0], np.array(obs_ref))
+    assert int(orc.f64pos[0]) == 1
+    for t in range(900):
+        acts = []
+        for a in env.agent_list:
+            d = np.asarray(a.target_location, np.float64) - np.asarray(a.location, np.float64)
+            acts.append(d * 1.5 if (t % 5 or t > 150) else d * 1.5 + np.array([0.3, -0.2]))
+        obs, rew, done, _ = env.step(acts, evaluate=bool(t % 11 == 0))
+        o_obs, o_rew, o_done = orc.step(np.array(acts, np.float64), evaluate=bool(t % 11 == 0))
+        loc, vel, pd, flags, cnt = _snap(env)
+        ctx = f"n={n} circular={circular} t={t}"
+        np.testing.assert_array_equal(o_done[0], np.array(done, np.uint8), err_msg=ctx)
+        np.testing.assert_array_equal(orc.loc[0], loc, err_msg=ctx)
+        np.testing.assert_array_equal(orc.vel[0], vel, err_msg=ctx)
+        np.testing.assert_array_equal(orc.prev_d[0], pd, err_msg=ctx)
+        np.testing.assert_array_equal(orc.flags[0], flags, err_msg=ctx)
+        np.testing.assert_array_equal(orc.counters[0, :3], cnt, err_msg=ctx)
+        ref_rew = np.array([float(r) for r in rew])
+        if circular:
+            np.testing.assert_array_equal(o_rew[0], ref_rew, err_msg=ctx)
+        else:
+            np.testing.assert_allclose(o_rew[0], ref_rew, rtol=1e-6, atol=1e-6, err_msg=ctx)
+        # neighbour columns of exactly tied agents depend on numpy's argsort tie order (platform dependent)
+        from golden_util import tie_agents
+        ties = tie_agents(loc, 15, True)
+        got, want = o_obs[0].copy(), np.array(obs)
+        got[ties, 4:] = 0; want[ties, 4:] = 0
+        np.testing.assert_array_equal(got, want, err_msg=ctx)
+    assert int(orc.counters[0, 1]) > 0, "nobody reached a target: scenario too short"
