@@ -16,7 +16,7 @@ F32, F64 = 0, 1
 
 # every symbol include/uavx.h declares (tests check the built library exports each of them)
 SYMBOLS = (
-    "uavx_version", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
+    "uavx_version", "uavx_selftest", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
     "uavx_num_agents", "uavx_set_config", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
     "uavx_set_state", "uavx_set_position_mode", "uavx_get_position_mode", "uavx_set_state_f64", "uavx_get_state_f64",
     "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
@@ -97,6 +97,7 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
     L.uavx_version.restype = i32
+    L.uavx_selftest.argtypes = [i32, ctypes.POINTER(ctypes.c_uint64)]
     L.uavx_strerror.restype = ctypes.c_char_p
     L.uavx_strerror.argtypes = [i32]
     L.uavx_create.argtypes = [ctypes.POINTER(Config), i64, i64, i32, ctypes.POINTER(vp)]

@@ -54,11 +54,30 @@ __device__ __forceinline__ void store8_wt(rsrc_t r, uint32_t byte_off, float2 v)
     __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)byte_off, 0, kAuxSc1);
 }
 
+// Correctly rounded sqrtf in 9 instructions instead of the compiler's 17: v_sqrt_f32 (<= 1 ulp) followed by the
+// same +-1 ulp residual test the compiler's IEEE expansion uses (e = s - c*r for the two neighbours c of r), but
+// WITHOUT its input scaling by 2^32 / output scaling by 2^-16, which only serves s < 2^-96 (v_sqrt_f32 flushes
+// denormal inputs and the residuals would underflow).  Squared distances of float32 world coordinates are either
+// 0 or far above that (two distinct points closer than 1.1e-14 m would need coordinates of that size), so the
+// scaled sequence sits behind a wave-uniform branch that is never taken in practice.  s = 0, +inf and NaN fall
+// through the residual tests unchanged (every compare is false).  The step kernel spends a fifth of its VALU
+// issue slots on square roots (prev / new target distance, N-1 neighbour distances); uavx_selftest() compares
+// this function with sqrtf on every float32 bit pattern.
+__device__ __forceinline__ float sqrt_rn(float s) {
+    if (__builtin_expect(__any((__float_as_uint(s) - 1u) < 0x0F7FFFFFu), 0)) return sqrtf(s);  // 0 < s < 2^-96
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float lo = __uint_as_float(__float_as_uint(r) - 1u), hi = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_lo = fmaf(-lo, r, s), e_hi = fmaf(-hi, r, s);
+    float out = (e_lo <= 0.f) ? lo : r;
+    out = (e_hi > 0.f) ? hi : out;
+    return out;
+}
+
 // np.linalg.norm on a float32 pair: fl(fl(x*x) + fl(y*y)) then correctly rounded sqrt (AG:33,51).
 __device__ __forceinline__ float norm32(float x, float y) {
     float a = x * x;
     float b = y * y;
-    return sqrtf(a + b);  // IEEE-rounded: built with -fhip-fp32-correctly-rounded-divide-sqrt
+    return sqrt_rn(a + b);
 }
 
 // np.clip on float64 scalars (AG:26-27): minimum(maximum(x, lo), hi)

@@ -206,7 +206,7 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const MultiParams &p, con
             const float ss = (j < m.i) ? sn : so;      // j<i already moved this step, j>i not yet
             r.step_sq_min = fminf(r.step_sq_min, (ss < p.sq_sense) ? ss : INFINITY);
         }
-        const float dn = (sn < p.sq_sense) ? sqrtf(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
+        const float dn = (sn < p.sq_sense) ? sqrt_rn(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
         const bool lt1 = dn < r.d1, lt2 = dn < r.d2;
         r.d2 = lt1 ? r.d1 : (lt2 ? dn : r.d2);
         r.j2 = lt1 ? r.j1 : (lt2 ? j : r.j2);
@@ -313,8 +313,8 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
     const bool in1 = s1 < p.sq_sense, in2 = s2 < p.sq_sense;  // AG:52
     Neigh r;
     r.step_sq_min = (step_min < p.sq_sense) ? step_min : INFINITY;
-    r.d1 = in1 ? sqrtf(s1) : INFINITY;
-    r.d2 = in2 ? sqrtf(s2) : INFINITY;
+    r.d1 = in1 ? sqrt_rn(s1) : INFINITY;
+    r.d2 = in2 ? sqrt_rn(s2) : INFINITY;
     r.j1 = in1 ? j1 : -1;
     r.j2 = in2 ? j2 : -1;
     return r;
@@ -891,6 +891,20 @@ __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_s
 
 #include "uavx_multi_f64.hpp"
 
+// uavx_selftest(): sqrt_rn() against the compiler's IEEE sqrtf on every float32 bit pattern 0 ... 0x7f800000 (all
+// non-negative values and +inf) plus the NaN / negative patterns of one exponent; counts differing results.
+__global__ __launch_bounds__(256) void sqrt_selftest_kernel(unsigned long long *mismatches) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned int bad = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= 0x7f800000ull + 0x00800000ull; b += stride) {
+        const float s = __uint_as_float((uint32_t)b);     // the last 2^23 patterns are NaNs
+        const uint32_t got = __float_as_uint(sqrt_rn(s)), want = __float_as_uint(sqrtf(s));
+        const bool both_nan = (got & 0x7fffffffu) > 0x7f800000u && (want & 0x7fffffffu) > 0x7f800000u;
+        bad += (got != want && !both_nan) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 }  // namespace uavx
 
 // ------------------------------------------------------------------------------------------------
@@ -1061,6 +1075,27 @@ struct DeviceGuard {
 extern "C" {
 
 int uavx_version(void) { return UAVX_VERSION; }
+
+int uavx_selftest(int device, uint64_t *mismatches) {
+    if (!mismatches) return UAVX_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UAVX_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return UAVX_ERR_INVALID_ARG;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return UAVX_ERR_HIP;
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc(&d, sizeof h) != hipSuccess) return UAVX_ERR_ALLOC;
+    hipError_t e = hipMemset(d, 0, sizeof h);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(256 * 32), dim3(256), 0, 0, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return UAVX_ERR_HIP;
+    *mismatches = h;
+    return UAVX_OK;
+}
 
 const char *uavx_strerror(int status) {
     switch (status) {

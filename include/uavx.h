@@ -96,6 +96,10 @@ typedef struct uavx_handle uavx_handle;       /* E x MultiUAVWorld2D */
 typedef struct uavx_uw_handle uavx_uw_handle; /* E x UAVWorld2D */
 
 int uavx_version(void);
+/* Hardware self test of the hand-written arithmetic the kernels rely on for bit-exactness: the 9-instruction
+ * correctly rounded square root (csrc/uavx_device.hpp sqrt_rn) against the compiler's IEEE sqrtf on every float32
+ * bit pattern.  *mismatches = number of differing results (0 expected).  Synchronous; about 10 ms. */
+int uavx_selftest(int device, uint64_t *mismatches);
 const char *uavx_strerror(int status);
 
 /* ---------------------------------------------------------------------------------------------

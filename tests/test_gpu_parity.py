@@ -530,6 +530,16 @@ def test_facade_uw_matches_reference_stream(amd):
     env.close()
 
 
+def test_hand_written_sqrt_is_ieee_on_every_float(amd):
+    """uavx_selftest: the kernels' 9-instruction square root equals the compiler's correctly rounded sqrtf on all
+    float32 bit patterns (0 ... +inf and a block of NaNs) on this device."""
+    import ctypes
+    from gym_uav_collision_avoidance_amd import _lib
+    bad = ctypes.c_uint64(123)
+    assert _lib.load().uavx_selftest(0, ctypes.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_errors_are_loud(amd):
     import torch
     env = amd.BatchedMultiUAVWorld2D(8, num_agents=4)

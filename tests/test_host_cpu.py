@@ -149,6 +149,7 @@ def test_abi_argument_validation_without_gpu():
         assert L.uavx_create(ctypes.byref(good), 8, 0, 0, ctypes.byref(h)) == -3     # UAVX_ERR_NO_DEVICE
     assert L.uavx_step(None, None, 0, 0, None, None, None, None) == -1
     assert L.uavx_destroy(None) == -1
+    assert L.uavx_selftest(0, None) == -1
     assert L.uavx_set_config(None, ctypes.byref(good)) == -1
     assert L.uavx_set_position_mode(None, 1, None) == -1 and L.uavx_get_position_mode(None) == -1
     assert L.uavx_set_state_f64(None, None, None) == -1 and L.uavx_get_state_f64(None, None, None) == -1
