@@ -2,7 +2,7 @@
 """Soak test (not part of the default suite): long closed-loop rollouts with auto-reset, device vs oracle,
 state / masks / reset streams compared bit-for-bit every step, observations and rewards every 16th step.
 
-    python tools/soak.py [steps] [envs]
+    python tools/soak.py [steps] [envs] [n1,n2,...]
 """
 import os
 import sys
@@ -19,8 +19,11 @@ from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-for n, kw in ((4, {}), (8, dict(x_size=40.0, y_size=40.0)), (10, {}), (3, dict(x_size=16.0, y_size=16.0, d_sense=6.0)),
-              (24, dict(x_size=70.0, y_size=70.0))):
+CASES = ((4, {}), (8, dict(x_size=40.0, y_size=40.0)), (10, {}), (3, dict(x_size=16.0, y_size=16.0, d_sense=6.0)),
+         (24, dict(x_size=70.0, y_size=70.0)))
+if len(sys.argv) > 3:   # e.g. "1,2,5,16,33,64": other agent counts, box scaled with sqrt(n)
+    CASES = tuple((int(k), dict(x_size=12.0 * int(k) ** 0.5 + 8, y_size=12.0 * int(k) ** 0.5 + 8)) for k in sys.argv[3].split(","))
+for n, kw in CASES:
     Ecur = E if n <= 10 else E // 4
     env = BatchedMultiUAVWorld2D(Ecur, num_agents=n, seed=100 + n, **kw)
     orc = oracle.OracleMulti(num_envs=Ecur, num_agents=n, nthreads=16, **kw)
