@@ -237,7 +237,8 @@ def main():
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (positions/obs) + f64 (velocity)", "data": "synthetic",
+            "dtype": "f32+f64", "dtype_note": "float32 positions / observations / rewards, float64 velocities, as the reference",
+            "data": "synthetic",
             "config": {"workload": f"{E} envs x {N} UAVs per GPU ({cfg_tag}), {world_name} defaults, "
                                    f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={mode}"
                                    + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else ""),
