@@ -8,12 +8,21 @@
 One "step" = one launch of the fused HIP step kernel over the whole batch (all agents of all envs
 advanced once, MUW:177-241).  Workload = BASELINE.json configs[2], the configuration the metric is
 quoted on: 65 536 envs x 4 UAVs per GPU (weak scaling: every rank owns 65 536 envs, sharded by env
-index with no step-path communication; one RCCL gather of episode metrics at the end of the timed
-region).  State, action ring and outputs are resident in HBM before the timed region starts.
+index with no step-path communication).  State, action ring and outputs are resident in HBM before a
+timed region starts.
+
+Timing contract.  W untimed warm-up steps, then the K-step region is timed `--repeats` times (default 5;
+SURVEY.md §8d / BASELINE.md §5.3: median of 5): every region is bracketed by barrier + synchronize on both
+sides, holds EXACTLY K step launches and nothing else (the episode-metrics read and the RCCL gather are
+timed separately as `gather_ms`; they are per-episode work, not per-step work), per region the MAX over
+ranks is taken, and `ms_per_step` / `value` are the MEDIAN region.  In graph mode the K launches are replayed
+from captured hipGraphs (chunks of `--ring` steps + one graph for the remainder, so that any K is a pure
+replay); `config.mode` says what actually ran and `config.graph_replays` how many replays one region held.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -23,27 +32,36 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+L3_BYTES = 256 * 2 ** 20       # Infinity Cache
 
 
-def algorithmic_bytes_per_env_step(n_agents):
-    """lean f32 SoA, 41 B read + 66 B write per agent-step + 24 B per-env counters."""
-    return 107 * n_agents + 24
+def algorithmic_bytes_per_env_step(n_agents, n_bodies=0):
+    """lean f32 SoA, 41 B read + 66 B write per agent-step + 24 B per-env counters; a scripted
+    body (BASELINE configs[4]) is a 16 B read + 16 B write record (no action, no observation / reward / done)."""
+    return 107 * n_agents + 24 + 32 * n_bodies
 
 
-def measured_traffic(E, N):
-    """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
-    produced by tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of this
-    command, with the gfx950 FETCH_SIZE x2 correction).  Only valid for the profiled grid."""
+def measured_traffic(kernel_name, grid_threads):
+    """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json, written by
+    tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs).  A summary is only used when it was
+    taken from THIS build of the kernels (hash of csrc/ + include/) and for this kernel and grid: a stale file
+    yields None rather than a number that no longer describes the code."""
     import glob
+    from gym_uav_collision_avoidance_amd import _lib
+    sha = _lib.source_hash()
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("_meta", {}).get("grid") == E * N and "hbm_traffic_bytes_per_launch" in d:
-            best = (d["hbm_traffic_bytes_per_launch"]["total"], os.path.basename(f))
+        for entry in (d.get("kernels") or [d]):
+            meta = entry.get("_meta", {})
+            if (meta.get("csrc_sha") == sha and meta.get("grid") == grid_threads
+                    and str(meta.get("kernel", "")).replace("void ", "").startswith(kernel_name)
+                    and "hbm_traffic_bytes_per_launch" in entry):
+                best = (entry["hbm_traffic_bytes_per_launch"]["total"], os.path.basename(f))
     return best
 
 
@@ -90,9 +108,147 @@ def cpu_baseline(n_agents, budget_s=12.0):
                 break
     except OSError:
         pass
-    return dict(value=out["all"], unit="env-steps/s", cores=cores, kind="port", cpu_model=model, host_cpus=os.cpu_count(),
-                sample=f"{E} envs x {n_agents} UAVs, oracle/uavx_oracle.c with OpenMP over envs on {cores} threads, ~{budget_s / 2:.0f} s",
-                single_thread_value=out["1"])
+    res = dict(value=out["all"], unit="env-steps/s", cores=cores, kind="port", cpu_model=model, host_cpus=os.cpu_count(),
+               sample=f"{E} envs x {n_agents} UAVs, oracle/uavx_oracle.c with OpenMP over envs on {cores} threads, ~{budget_s / 2:.0f} s",
+               single_thread_value=out["1"])
+    # the unmodified Python reference cannot travel to the GPU box: its timing is taken in the build container by
+    # tools/time_reference.py and attached here with its provenance
+    import glob
+    refs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_reference_cpu.json")))
+    if refs:
+        try:
+            ref = json.load(open(refs[-1]))
+            row = next((r for r in ref["rows"] if r["world"] == "MultiUAVWorld2D" and r["num_agents"] == n_agents), None)
+            if row:
+                res["reference_python"] = dict(value=row["env_steps_per_s"], unit="env-steps/s", cores=1,
+                                               provenance=f"{os.path.basename(refs[-1])}: {ref['provenance']}")
+        except Exception:
+            pass
+    return res
+
+
+class Stepper:
+    """K step launches as pure hipGraph replays (chunks of R steps + one graph for the remainder) or, in launch
+    mode / if capture fails, as K eager ctypes -> hipLaunchKernel calls."""
+
+    def __init__(self, step, ring, device, mode):
+        self.step, self.ring, self.R, self.device, self.mode = step, ring, int(ring.shape[0]), device, mode
+        self.graphs = {}
+
+    def _capture(self, n):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime during capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for i in range(n):
+                self.step(self.ring[i])
+        return g
+
+    def prepare(self, K):
+        """Captures what run(K) needs.  Capture executes nothing, so the env state is untouched."""
+        if self.mode != "graph":
+            return
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):   # a few eager calls on the capture stream first (lazy init outside the capture)
+            for i in range(3):
+                self.step(self.ring[i % self.R])
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.capture_warmup = 3
+        full, rem = divmod(K, self.R)
+        try:
+            for n in ({self.R} if full else set()) | ({rem} if rem else set()):
+                if n not in self.graphs:
+                    self.graphs[n] = self._capture(n)
+        except Exception as exc:  # eager stepping is GPU-bound as well (4.3 us host cost per call): fall back
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); using --mode launch", file=sys.stderr)
+            self.graphs, self.mode = {}, "launch"
+            torch.cuda.synchronize(self.device)
+
+    def replays(self, K):
+        if self.mode != "graph":
+            return 0
+        full, rem = divmod(K, self.R)
+        return full + (1 if rem else 0)
+
+    def run(self, K):
+        if self.mode == "graph":
+            full, rem = divmod(K, self.R)
+            for _ in range(full):
+                self.graphs[self.R].replay()
+            if rem:
+                self.graphs[rem].replay()
+        else:
+            for i in range(K):
+                self.step(self.ring[i % self.R])
+
+
+def timed_regions(stepper, K, repeats, device, dist=None):
+    """`repeats` regions of exactly K step launches; returns per-region (wall s, device ms) lists (this rank)."""
+    walls, devs = [], []
+    for _ in range(repeats):
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        stepper.run(K)
+        ev1.record()
+        while not ev1.query():      # spin instead of a blocking wait: the wake-up latency of a sleeping host thread
+            pass                    # (tens of us) would otherwise be charged to a K-step region of ~100 us
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        walls.append(t1 - t0)
+        devs.append(ev0.elapsed_time(ev1))  # HIP events on the stream the kernels were launched on
+    return walls, devs
+
+
+def single_step_latency(step, ring, device, trials=200):
+    """Host-visible latency of ONE step from an idle stream: launch -> kernel done (median, us).  What a caller that
+    needs every result before it can act (the single-env façades, small batches) pays per step."""
+    lat = []
+    ev = torch.cuda.Event()
+    for i in range(trials):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        step(ring[i % ring.shape[0]])
+        ev.record()
+        while not ev.query():
+            pass
+        lat.append((time.perf_counter() - t0) * 1e6)
+    return statistics.median(lat)
+
+
+def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60):
+    """The same step kernel on a batch whose working set (state + double-buffered outputs + action ring, ~0.9 GB at
+    N=4) is several times the 256 MiB Infinity Cache, i.e. a launch that really streams from HBM."""
+    from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D
+    env = BatchedMultiUAVWorld2D(E, num_agents=N + bodies, device=device, seed=0, **(dict(num_bodies=bodies) if bodies else {}))
+    L = N
+    ring = polar_actions(gen, (6, E, L), float(np.sqrt(200.0)), device)
+    env.reset()
+    st = Stepper(env.step, ring, device, "graph")
+    st.prepare(steps)
+    st.run(warmup)
+    walls, devs = timed_regions(st, steps, 3, device)
+    kernel_s = statistics.median(devs) * 1e-3 / steps
+    b = algorithmic_bytes_per_env_step(N, bodies) * E
+    ws = working_set_bytes(E, N + bodies, L, ring.shape[0])
+    env.close()
+    del ring, env
+    torch.cuda.empty_cache()
+    return dict(bound="hbm", achieved=b / kernel_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b / kernel_s / 1e9 / HBM_PEAK_GBS,
+                traffic=None, bytes_per_launch=b, kernel_us=kernel_s * 1e6, envs=E, agents=N, steps=steps,
+                working_set_bytes=ws, note="working set >> 256 MiB Infinity Cache: HBM-resident stream; "
+                                           "achievable HBM rate on MI355X is ~6.3 TB/s (0.79 of the 8 TB/s spec peak)")
+
+
+def working_set_bytes(E, n_slots, n_learners, ring_len):
+    """Bytes one pass over the action ring touches: state (40 B per agent slot), both obs buffers, rew, done, ring."""
+    return E * (n_slots * 40 + n_learners * (2 * 40 + 4 + 1) + ring_len * n_learners * 8) + E * 48
 
 
 def main():
@@ -100,18 +256,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=5, help="timed K-step regions; the median is reported")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--agents", type=int, default=4, help="learning UAVs per env")
+    ap.add_argument("--bodies", type=int, default=0,
+                    help="scripted dynamic obstacles per env, stepped in-kernel (BASELINE configs[4]: --agents 8 --bodies 16)")
     ap.add_argument("--world", choices=("multi", "uw"), default="multi",
                     help="multi: MultiUAVWorld2D (headline); uw: UAVWorld2D (single UAV, BASELINE configs[1] family)")
     ap.add_argument("--fused", action="store_true",
                     help="multi only: drive uavx_step_ex (polar action conversion, agent0-done auto-reset with a "
                          "1500-step cap, episode statistics) instead of the bare step")
     ap.add_argument("--mode", choices=("graph", "launch"), default="graph",
-                    help="graph: steps replayed from a captured hipGraph (one kernel node per step); "
+                    help="graph: steps replayed from captured hipGraphs (one kernel node per step); "
                          "launch: one ctypes->hipLaunchKernel per step")
     ap.add_argument("--ring", type=int, default=50, help="distinct action batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the HBM-sized second roofline point (1 Mi envs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +291,7 @@ def main():
     # UAVX_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N>1 code path -- RCCL communicator,
     # gather, barriers -- with a single rank, to exercise it on a one-GPU box.  Never set by the driver.
     distributed = world > 1 or os.environ.get("UAVX_FORCE_DIST") == "1"
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -142,116 +303,120 @@ def main():
     from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D, BatchedUAVWorld2D
     from gym_uav_collision_avoidance_amd.sharding import gather_episode_metrics, summarize_metrics
 
-    E, N, K, W = args.envs, args.agents, args.steps, args.warmup
+    E, N, B, K, W = args.envs, args.agents, args.bodies, args.steps, args.warmup
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    nt = lambda n: n if n in (1, 2, 4, 8) else 0
     if args.world == "uw":
-        N = 1
+        N, B = 1, 0
         env = BatchedUAVWorld2D(E, device=device, env_offset=rank * E, seed=0)
         ring = polar_actions(gen, (args.ring, E), float(np.sqrt(288.0)), device)  # ||(12,12)||, test_sac.py:77
         step = env.step
-        bytes_per_env_step, kernel_name = 93, "uavx::uw_step_kernel<false>"
+        bytes_per_env_step, kernel_name = 93, "uavx::uw_step_kernel"
+        block = 64
     else:
-        env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, env_offset=rank * E, seed=0)
-        bytes_per_env_step = algorithmic_bytes_per_env_step(N)
+        env = BatchedMultiUAVWorld2D(E, num_agents=N + B, device=device, env_offset=rank * E, seed=0,
+                                     **(dict(num_bodies=B) if B else {}))
+        bytes_per_env_step = algorithmic_bytes_per_env_step(N, B)
+        block = 64
         if args.fused:
             ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
             step = lambda a: env.step_ex(a, polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
-            kernel_name = f"uavx::step_ex_kernel<{N if N in (1, 2, 4, 8) else 0},false>"
+            kernel_name = f"uavx::step_ex_kernel<{nt(N + B)}"
         else:
             ring = polar_actions(gen, (args.ring, E, N), float(np.sqrt(200.0)), device)
             step = env.step
-            kernel_name = f"uavx::step_kernel<{N if N in (1, 2, 4, 8) else 0},false>"
+            kernel_name = f"uavx::step_kernel<{nt(N + B)}"
     env.reset()
 
-    R = args.ring
-    mode = args.mode
-    graph = None
-    if mode == "graph":
-        # capture R consecutive steps (each reading its own action batch) into one hipGraph
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for i in range(3):
-                step(ring[i % R])
-        torch.cuda.current_stream(device).wait_stream(side)
-        try:
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime during capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                for i in range(R):
-                    step(ring[i])
-        except Exception as exc:  # eager stepping is GPU-bound as well (4.3 us host cost per call): fall back
-            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); using --mode launch", file=sys.stderr)
-            graph, mode = None, "launch"
-            torch.cuda.synchronize(device)
-    if graph is not None:
-        def run(nsteps):
-            full, rem = divmod(nsteps, R)
-            for _ in range(full):
-                graph.replay()
-            for i in range(rem):
-                step(ring[i])
-    else:
-        def run(nsteps):
-            for i in range(nsteps):
-                step(ring[i % R])
-
-    run(W)
+    stepper = Stepper(step, ring, device, args.mode)
+    stepper.prepare(K)
+    for i in range(W):  # W untimed warm-up steps (eager launches; capture itself executes nothing)
+        step(ring[i % args.ring])
+    read_counters = (lambda: env.metrics()) if args.world == "multi" else (lambda: env.get_state()["counters"])
     if distributed:
-        gather_episode_metrics(env.metrics() if args.world == "multi" else env.get_state()["counters"], dst=0)  # warm the communicator
+        gather_episode_metrics(read_counters(), dst=0)  # warm the communicator
+
+    walls, devs = timed_regions(stepper, K, max(1, args.repeats), device, dist)
+
+    # episode-metrics path (test_sac_multi.py:164-165): counters read + ONE gather to rank 0, timed on its own
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(device)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(K)
-    ev1.record()
-    counters = env.metrics() if args.world == "multi" else env.get_state()["counters"]
+    tg = time.perf_counter()
+    counters = read_counters()
     gathered = gather_episode_metrics(counters, dst=0) if distributed else counters
     torch.cuda.synchronize(device)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
+    gather_s = time.perf_counter() - tg
 
     if distributed:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cpu" if rehearsal else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+        t = torch.tensor([walls, devs, [gather_s] * len(walls)], dtype=torch.float64, device="cpu" if rehearsal else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # per region: the slowest rank
+        walls, devs, gather_s = t[0].tolist(), t[1].tolist(), float(t[2][0])
 
     if rank == 0:
         total_envs = E * world
+        elapsed = statistics.median(walls)
+        dev_ms = statistics.median(devs)
         value = total_envs * K / elapsed
         bytes_per_launch = bytes_per_env_step * E
-        kernel_s = dev_ms * 1e-3 / K  # average per-step device time over the timed region
+        kernel_s = dev_ms * 1e-3 / K  # average per-step device time over the median timed region
         achieved = bytes_per_launch / kernel_s / 1e9
         summ = summarize_metrics(gathered, N) if args.world == "multi" else {"mean_steps": float(gathered[:, 0].double().mean())}
         if args.fused:
             summ["ended_episodes"] = env.evaluation_summary()
-        traffic = measured_traffic(E, N) if (args.world == "multi" and not args.fused) else None
+        slots = N + B
+        grid_threads = -(-E // max(1, 64 // slots)) * 64 if args.world == "multi" else -(-E // block) * block
+        traffic = measured_traffic(kernel_name, grid_threads)
+        ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
         world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
-        cfg_tag = "BASELINE.json configs[2]" if (args.world == "multi" and E == 65536 and N == 4) else "non-headline size"
+        if args.world == "multi" and E == 65536 and N == 4 and B == 0:
+            cfg_tag = "BASELINE.json configs[2]"
+        elif args.world == "multi" and E == 65536 and N == 8 and B == 16:
+            cfg_tag = "BASELINE.json configs[4]: 8 learners + 16 scripted dynamic obstacles (extension, parity unpinned by the reference)"
+        else:
+            cfg_tag = "non-headline size"
+        mode = stepper.mode
+        replays = stepper.replays(K)
+        if mode == "graph" and replays == 0:
+            mode = "launch"
+        note = (f"working set {ws / 2 ** 20:.0f} MiB (state + double-buffered outputs + {args.ring}-batch action ring) "
+                + ("fits the 256 MiB Infinity Cache: FETCH/WRITE_SIZE count fabric requests incl. L3 hits, so this point is "
+                   "L3-resident, not HBM-streaming; see roofline_large for the HBM-sized batch" if ws < L3_BYTES else
+                   "exceeds the 256 MiB Infinity Cache: HBM-streaming"))
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+f64", "dtype_note": "float32 positions / observations / rewards, float64 velocities, as the reference",
-            "data": "synthetic",
-            "config": {"workload": f"{E} envs x {N} UAVs per GPU ({cfg_tag}), {world_name} defaults, "
-                                   f"polar U(-1,1)^2 actions from a {R}-batch HBM ring, mode={mode}"
+            "data": "synthetic", "repeats": len(walls), "repeat_ms_per_step": [w * 1e3 / K for w in walls],
+            "config": {"workload": f"{E} envs x {N} UAVs" + (f" + {B} scripted bodies" if B else "") + f" per GPU ({cfg_tag}), "
+                                   f"{world_name} defaults, polar U(-1,1)^2 actions from a {args.ring}-batch HBM ring, mode={mode}"
                                    + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else ""),
-                       "envs_per_gpu": E, "agents": N, "parallelism": f"env-index shard x{world}", "mode": mode},
+                       "envs_per_gpu": E, "agents": N, "bodies": B, "parallelism": f"env-index shard x{world}", "mode": mode,
+                       "graph_replays": replays},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
-                         "kernel": kernel_name},
+                         "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else ",false>"), "note": note},
+            "gather_ms": gather_s * 1e3,
+            "gather_note": "counter read + one gather of [E,4] episode metrics to rank 0 (once per episode, not per step); "
+                           "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",
+            "ms_per_step_incl_amortised_gather": elapsed * 1e3 / K + gather_s * 1e3 / 1500.0,
             "episode_metrics": summ,
+            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * len(walls),
         }
+        if world == 1:
+            line["latency_us"] = {"single_step_launch_to_done": single_step_latency(step, ring, device),
+                                  "kernel": kernel_s * 1e6,
+                                  "note": "one step from an idle stream, host-visible; small batches are bound by this, not by bytes"}
+        if world == 1 and not args.no_large and args.world == "multi" and not args.fused and E < (1 << 20):
+            env.close()
+            del ring
+            torch.cuda.empty_cache()
+            line["roofline_large"] = large_batch_point(N, device, gen, bodies=B)
         if world == 1 and not args.no_cpu_baseline and args.world == "multi":
             line["cpu_baseline"] = cpu_baseline(N)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     env.close()
     if distributed:

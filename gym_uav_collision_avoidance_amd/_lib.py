@@ -72,13 +72,51 @@ class UWStepArgs(ctypes.Structure):  # uavx_uw_step_args
 _lib = None
 
 
+def source_hash():
+    """Identity of the kernel sources a measurement belongs to: sha256 over csrc/*.hip, csrc/*.hpp and
+    include/uavx.h (first 16 hex digits).  profiles/*_pmc_summary.json carry it; bench.py drops a summary whose
+    hash is not the one of the sources in the tree."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "uavx.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
-    """hipcc build of csrc/ into csrc/libuavx.so (gfx950).  Cross-compiles without a GPU."""
-    args = ["make", "-C", CSRC]
-    if force:
-        args.append("-B")
-    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    """hipcc build of csrc/ into csrc/libuavx.so (gfx950).  Cross-compiles without a GPU.  Several processes may
+    get here at once (torchrun ranks on a fresh checkout): the build runs under an exclusive file lock into a
+    temporary name and is renamed into place, so nobody ever maps a half-written library."""
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and os.path.exists(LIB_PATH) and _up_to_date():
+                return LIB_PATH
+            tmp = f"libuavx.so.tmp{os.getpid()}"
+            proc = subprocess.run(["make", "-C", CSRC, "-B", f"OUT={tmp}"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                  text=True)
+            if proc.returncode != 0:
+                try:
+                    os.unlink(os.path.join(CSRC, tmp))
+                except OSError:
+                    pass
+                raise RuntimeError(f"uavx: building {LIB_PATH} failed (make exit {proc.returncode}):\n{proc.stdout[-4000:]}")
+            os.replace(os.path.join(CSRC, tmp), LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+def _up_to_date():
+    import glob
+    srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + [
+        os.path.join(os.path.dirname(_HERE), "include", "uavx.h"), os.path.join(CSRC, "Makefile")]
+    return os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)
 
 
 def load():
@@ -86,10 +124,9 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        try:  # not built yet (fresh checkout): compile the HIP library once; this is a build, not a fallback
-            build()
-        except Exception:
-            pass
+        # not built yet (fresh checkout): compile the HIP library once; this is a build, not a fallback, and a
+        # compile error is raised as such instead of being reported as "not built"
+        build()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {CSRC}` "

@@ -18,20 +18,26 @@ def shard_range(total_envs, world_size, rank):
     return offset, count
 
 
-def gather_episode_metrics(local, dst=0, group=None):
-    """Gathers per-env metric rows ([E_local, C] tensor; any dtype) from every rank to `dst` in global
-    env order.  Returns the concatenated [E_total, C] tensor on dst, None elsewhere.  Ranks may own
-    different numbers of envs (shard_range); rows are padded to the largest shard for the gather."""
+def gather_episode_metrics(local, dst=0, group=None, total_envs=None):
+    """Gathers per-env metric rows ([E_local, C] tensor; any dtype) from every rank to `dst` in global env order
+    with ONE collective (`gather`; RCCL over xGMI with backend "nccl") and no host synchronisation before it.
+    Returns the concatenated [E_total, C] tensor on dst, None elsewhere.
+
+    Shard sizes follow from the layout, not from communication: total_envs=None means every rank owns the same
+    number of rows (the weak-scaling layout of bench.py); total_envs=T means the contiguous split of shard_range(T,
+    world, rank), whose first T % world ranks own one extra row -- rows are then padded to the largest shard."""
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if dist.get_backend(group) == "gloo" and local.is_cuda:
         local = local.cpu()  # rehearsal backend: gloo gathers host tensors
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if total_envs is None:
+        sizes = [int(local.shape[0])] * world
+    else:
+        sizes = [shard_range(total_envs, world, r)[1] for r in range(world)]
+        if sizes[rank] != local.shape[0]:
+            raise ValueError(f"rank {rank} holds {local.shape[0]} rows, shard_range({total_envs}, {world}, {rank}) says {sizes[rank]}")
     width = max(sizes)
     padded = local
     if local.shape[0] != width:
@@ -43,6 +49,23 @@ def gather_episode_metrics(local, dst=0, group=None):
     if rank != dst:
         return None
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+def reduce_episode_totals(counters, num_agents, dst=0, group=None):
+    """When only SR / CR / mean episode length are wanted (test_sac_multi.py:174-176), four scalars travel instead of
+    E rows: ONE `reduce` (ncclReduce, sum) of [sum steps, sum target_reach_count, sum collision_count, envs] to `dst`.
+    counters: this rank's [E_local, >=3] rows (steps, reach, coll, ...).  Returns the summary dict on dst, None elsewhere."""
+    c = counters[:, :3].to(torch.float64)
+    tot = torch.cat([c.sum(dim=0), torch.tensor([float(c.shape[0])], dtype=torch.float64, device=c.device)])
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend(group) == "gloo" and tot.is_cuda:
+            tot = tot.cpu()
+        dist.reduce(tot, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) != dst:
+            return None
+    steps, reach, coll, envs = (float(x) for x in tot)
+    return dict(success_rate=reach / (num_agents * envs), collision_rate=coll / (num_agents * envs), mean_steps=steps / envs,
+                episodes=int(envs))
 
 
 def summarize_metrics(counters, num_agents):
@@ -67,12 +90,12 @@ def make_sharded_env(total_envs, device=None, group=None, seed=0, **env_kwargs):
     return BatchedMultiUAVWorld2D(count, device=device, env_offset=offset, seed=seed, **env_kwargs)
 
 
-def gather_evaluation_summary(env, dst=0, group=None):
+def gather_evaluation_summary(env, dst=0, group=None, total_envs=None):
     """SR / CR / score over the ended episodes of ALL shards (one gather of [E_local, 6] rows)."""
     st = env.episode_stats()
     rows = torch.stack([st["episodes"].float(), st["steps"].float(), st["reach"].float(), st["coll"].float(),
                         st["return0"], st["score"]], dim=1)
-    allrows = gather_episode_metrics(rows, dst=dst, group=group)
+    allrows = gather_episode_metrics(rows, dst=dst, group=group, total_envs=total_envs)
     if allrows is None:
         return None
     a = allrows.double().sum(dim=0)

@@ -34,6 +34,24 @@ def test_single_gpu_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 400.0   # > 5 % of peak or something broke
     assert d["value"] > 5e7, "target of BASELINE.json: >= 50 M env-steps/s"
     assert abs(d["value"] - 65536 * 300 / (d["ms_per_step"] * 300 / 1e3)) / d["value"] < 1e-6
+    assert d["repeats"] == 5 and len(d["repeat_ms_per_step"]) == 5
+    assert d["ms_per_step"] == pytest.approx(sorted(d["repeat_ms_per_step"])[2])          # the median region
+    assert d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 6            # 300 = 6 x 50-step graphs
+    assert "L3-resident" in r["note"] and d["gather_ms"] > 0 and d["latency_us"]["single_step_launch_to_done"] > 0
+    big = d["roofline_large"]
+    assert big["envs"] == 1 << 20 and big["working_set_bytes"] > 2 * 256 * 2 ** 20 and 0.3 < big["frac"] < 1.0
+
+
+def test_driver_sized_run_is_a_pure_graph_replay():
+    """The driver's round-end command (--steps 20 --warmup 5): 20 < ring length, so the region must be ONE replay of a
+    20-node graph (round 1 silently ran it as 20 eager launches and reported half the rate the kernel earns)."""
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                          "--no-large"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 1
+    assert d["steps_executed"] == 3 + 5 + 5 * 20
+    assert d["value"] > 7e9, d["value"]   # 20 x ~6.3 us of kernels + one graph launch; 9-10 G on a quiet box
 
 
 def test_two_rank_rehearsal():
@@ -48,7 +66,8 @@ def test_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["parallelism"] == "env-index shard x2"
     assert abs(d["value"] - 2 * 8192 * 200 / (d["ms_per_step"] * 200 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
     assert "cpu_baseline" not in d
-    assert d["episode_metrics"]["mean_steps"] == 223.0   # 3 capture-warmup + 20 warmup + 200 timed steps on every env of both shards
+    assert d["steps_executed"] == 3 + 20 + 5 * 200        # capture warm-up + warm-up + 5 timed regions
+    assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"])   # ... on every env of both shards
 
 
 def test_rccl_code_path_with_one_rank():
@@ -63,4 +82,4 @@ def test_rccl_code_path_with_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["config"]["mode"] == "graph", (d["config"], out.stderr[-1500:])
-    assert d["episode_metrics"]["mean_steps"] == 223.0
+    assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"]) == 1023.0

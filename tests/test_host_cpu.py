@@ -96,16 +96,26 @@ def _free_port():
 
 def _gather_worker(rank, world, port, total, q):
     import torch.distributed as dist
-    from gym_uav_collision_avoidance_amd.sharding import gather_episode_metrics, shard_range, summarize_metrics
+    from gym_uav_collision_avoidance_amd.sharding import (gather_episode_metrics, reduce_episode_totals, shard_range,
+                                                        summarize_metrics)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     off, cnt = shard_range(total, world, rank)
     rows = torch.arange(off, off + cnt, dtype=torch.int32)
     local = torch.stack([rows * 3, rows % 5, rows % 2, torch.ones_like(rows)], dim=1)  # fake counters keyed by global env
-    out = gather_episode_metrics(local, dst=0)
+    # exactly ONE collective per call: count what torch.distributed is asked to do
+    calls = []
+    for name in ("gather", "all_gather", "reduce", "all_reduce", "broadcast"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o, n: (lambda *a, **k: (calls.append(n), o(*a, **k))[1]))(orig, name))
+    out = gather_episode_metrics(local, dst=0, total_envs=total)
+    assert calls == ["gather"], calls
+    calls.clear()
+    red = reduce_episode_totals(local, 4, dst=0)
+    assert calls == ["reduce"], calls
     if rank == 0:
-        q.put((out.numpy(), summarize_metrics(out, 4)))
+        q.put((out.numpy(), summarize_metrics(out, 4), red))
     else:
-        assert out is None
+        assert out is None and red is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -118,7 +128,7 @@ def test_gloo_world2_metrics_gather():
     procs = [ctx.Process(target=_gather_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, summary = q.get(timeout=120)
+    got, summary, reduced = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -126,6 +136,10 @@ def test_gloo_world2_metrics_gather():
     want = np.stack([rows * 3, rows % 5, rows % 2, np.ones_like(rows)], axis=1)
     np.testing.assert_array_equal(got, want)
     assert summary["success_rate"] == pytest.approx((rows % 5).sum() / (4 * total))
+    # the 4-scalar reduce path gives the same SR / CR / mean length without moving the rows
+    assert reduced["episodes"] == total and reduced["success_rate"] == pytest.approx(summary["success_rate"])
+    assert reduced["collision_rate"] == pytest.approx(summary["collision_rate"])
+    assert reduced["mean_steps"] == pytest.approx(summary["mean_steps"])
 
 
 def test_abi_argument_validation_without_gpu():

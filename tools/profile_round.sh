@@ -1,13 +1,40 @@
 #!/bin/bash
-# Regenerates the rocprofv3 evidence under gpurun_out/prof_* (run on the GPU box through gpurun), then
+# Regenerates the rocprofv3 evidence under gpurun_out/prof/<shape>/<pass>/ (run on the GPU box through gpurun), then
 #   python tools/summarize_profiles.py rNN   condenses it into profiles/.
-# Kernel trace and each counter group are separate runs (counter collection serialises and slows kernels).
+# usage: tools/profile_round.sh [calib] [ExN[+B] ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8 65536x24
+# Kernel trace and each counter group are separate runs (counter collection serialises and slows kernels); the
+# program itself follows `--` (no env / bash -c hop).  TCC has 4 counter slots per pass, SQ 8.
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq
-rocprofv3 --output-format csv --kernel-trace --stats -d gpurun_out/prof_kt -o runc -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d gpurun_out/prof_fetch -o runc -- python3 bench.py --steps 300 --warmup 30 --mode launch --no-cpu-baseline > gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d gpurun_out/prof_write -o runc -- python3 bench.py --steps 300 --warmup 30 --mode launch --no-cpu-baseline > gpurun_out/prof_write.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d gpurun_out/prof_sq -o runc -- python3 bench.py --steps 300 --warmup 30 --mode launch --no-cpu-baseline > gpurun_out/prof_sq.log 2>&1
-find gpurun_out/prof_* -name "*.csv" | head -20
+OUT=gpurun_out/prof
+mkdir -p $OUT
+python3 -c "from gym_uav_collision_avoidance_amd import _lib; import json; json.dump({'csrc_sha': _lib.source_hash()}, open('$OUT/meta.json','w'))"
+declare -A PASS
+PASS[fetch]="FETCH_SIZE"
+PASS[write]="WRITE_SIZE"
+PASS[tcc_hit]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
+PASS[tcc_ea]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_WRREQ_sum"
+PASS[sq]="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+PASS[sq2]="SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM"
+for arg in "$@"; do
+  if [ "$arg" = calib ]; then
+    d=$OUT/calib; rm -rf $d; mkdir -p $d
+    for p in fetch write tcc_ea tcc_hit; do
+      rocprofv3 --output-format csv --kernel-trace --pmc ${PASS[$p]} -d $d/$p -o run -- tools/micro/fetch_calib > $d/$p.log 2>&1
+      echo "calib $p done"
+    done
+    continue
+  fi
+  shape=${arg%%+*}; bodies=0; [[ "$arg" == *+* ]] && bodies=${arg##*+}
+  E=${shape%%x*}; N=${shape##*x}
+  d=$OUT/$arg; rm -rf $d; mkdir -p $d
+  BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large"
+  rocprofv3 --output-format csv --kernel-trace --stats -d $d/kt -o run -- python3 bench.py $BARGS --steps 1000 --warmup 100 > $d/kt.log 2>&1
+  echo "$arg kt done"
+  for p in fetch write tcc_hit tcc_ea sq sq2; do
+    rocprofv3 --output-format csv --kernel-trace --pmc ${PASS[$p]} -d $d/$p -o run -- python3 bench.py $BARGS --steps 100 --warmup 20 --repeats 2 --mode launch > $d/$p.log 2>&1
+    echo "$arg $p done"
+  done
+done
+find $OUT -name "*.csv" | wc -l
