@@ -226,7 +226,7 @@ def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60)
     """The same step kernel on a batch whose working set (state + double-buffered outputs + action ring, ~0.9 GB at
     N=4) is several times the 256 MiB Infinity Cache, i.e. a launch that really streams from HBM."""
     from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D
-    env = BatchedMultiUAVWorld2D(E, num_agents=N + bodies, device=device, seed=0, **(dict(num_bodies=bodies) if bodies else {}))
+    env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, seed=0, **(dict(num_bodies=bodies) if bodies else {}))
     L = N
     ring = polar_actions(gen, (6, E, L), float(np.sqrt(200.0)), device)
     env.reset()
@@ -314,18 +314,18 @@ def main():
         bytes_per_env_step, kernel_name = 93, "uavx::uw_step_kernel"
         block = 64
     else:
-        env = BatchedMultiUAVWorld2D(E, num_agents=N + B, device=device, env_offset=rank * E, seed=0,
+        env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, env_offset=rank * E, seed=0,
                                      **(dict(num_bodies=B) if B else {}))
         bytes_per_env_step = algorithmic_bytes_per_env_step(N, B)
         block = 64
         if args.fused:
             ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
             step = lambda a: env.step_ex(a, polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
-            kernel_name = f"uavx::step_ex_kernel<{nt(N + B)}"
+            kernel_name = f"uavx::step_ex_kernel<{0 if B else nt(N)}"
         else:
             ring = polar_actions(gen, (args.ring, E, N), float(np.sqrt(200.0)), device)
             step = env.step
-            kernel_name = f"uavx::step_kernel<{nt(N + B)}"
+            kernel_name = f"uavx::step_kernel<{0 if B else nt(N)}"
     env.reset()
 
     stepper = Stepper(step, ring, device, args.mode)
@@ -365,7 +365,8 @@ def main():
         if args.fused:
             summ["ended_episodes"] = env.evaluation_summary()
         slots = N + B
-        grid_threads = -(-E // max(1, 64 // slots)) * 64 if args.world == "multi" else -(-E // block) * block
+        epw = min(64 // N, 192 // slots) if B else 64 // N   # envs per wavefront (uavx_create)
+        grid_threads = -(-E // epw) * 64 if args.world == "multi" else -(-E // block) * block
         traffic = measured_traffic(kernel_name, grid_threads)
         ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
         world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
@@ -397,7 +398,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
-                         "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else ",false>"), "note": note},
+                         "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else (",false,true>" if B else ",false,false>")),
+                         "note": note},
             "gather_ms": gather_s * 1e3,
             "gather_note": "counter read + one gather of [E,4] episode metrics to rank 0 (once per episode, not per step); "
                            "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",

@@ -11,13 +11,15 @@ LIB_PATH = os.path.join(CSRC, "libuavx.so")
 OBS_DIM = 10
 UW_OBS_DIM = 4
 MAX_AGENTS = 64
-FLAG_DONE, FLAG_COLLIDED, FLAG_VEL_F32 = 1, 2, 4
+MAX_LEVELS = 16
+FLAG_DONE, FLAG_COLLIDED, FLAG_VEL_F32, FLAG_INACTIVE = 1, 2, 4, 32
 F32, F64 = 0, 1
 
 # every symbol include/uavx.h declares (tests check the built library exports each of them)
 SYMBOLS = (
     "uavx_version", "uavx_selftest", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
-    "uavx_num_agents", "uavx_set_config", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
+    "uavx_num_agents", "uavx_set_config", "uavx_set_body_rule", "uavx_num_bodies", "uavx_get_bodies", "uavx_set_bodies",
+    "uavx_set_curriculum", "uavx_set_env_levels", "uavx_get_env_levels", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
     "uavx_set_state", "uavx_set_position_mode", "uavx_get_position_mode", "uavx_set_state_f64", "uavx_get_state_f64",
     "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
     "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
@@ -30,7 +32,17 @@ class Config(ctypes.Structure):
     _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("max_speed", ctypes.c_double),
                 ("max_acceleration", ctypes.c_double), ("collider_radius", ctypes.c_double),
                 ("d_sense", ctypes.c_double), ("tau", ctypes.c_double), ("num_agents", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("num_bodies", ctypes.c_int32)]
+
+
+class BodyRule(ctypes.Structure):  # uavx_body_rule
+    _fields_ = [("speed", ctypes.c_double), ("period", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("seed", ctypes.c_uint64)]
+
+
+class Level(ctypes.Structure):  # uavx_level
+    _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("collider_radius", ctypes.c_double),
+                ("d_sense", ctypes.c_double), ("n_active", ctypes.c_int32), ("b_active", ctypes.c_int32)]
 
 
 class UWConfig(ctypes.Structure):
@@ -59,7 +71,9 @@ class StepArgs(ctypes.Structure):  # uavx_step_args
     _fields_ = [("actions", ctypes.c_void_p), ("action_dtype", ctypes.c_int32), ("action_mode", ctypes.c_int32),
                 ("evaluate", ctypes.c_int32), ("reset_policy", ctypes.c_int32), ("step_cap", ctypes.c_uint32),
                 ("track_returns", ctypes.c_int32), ("seed", ctypes.c_uint64), ("obs", ctypes.c_void_p),
-                ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p)]
+                ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p),
+                ("ended", ctypes.c_void_p), ("truncated", ctypes.c_void_p)]
+
 
 class UWStepArgs(ctypes.Structure):  # uavx_uw_step_args
     _fields_ = [("actions", ctypes.c_void_p), ("action_dtype", ctypes.c_int32), ("action_mode", ctypes.c_int32),
@@ -145,6 +159,13 @@ def load():
     L.uavx_num_envs.restype = i64
     L.uavx_num_agents.argtypes = [vp]
     L.uavx_set_config.argtypes = [vp, ctypes.POINTER(Config)]
+    L.uavx_set_body_rule.argtypes = [vp, ctypes.POINTER(BodyRule)]
+    L.uavx_num_bodies.argtypes = [vp]
+    L.uavx_get_bodies.argtypes = [vp, vp, vp]
+    L.uavx_set_bodies.argtypes = [vp, vp, vp]
+    L.uavx_set_curriculum.argtypes = [vp, ctypes.POINTER(Level), i32, i32, i32, vp]
+    L.uavx_set_env_levels.argtypes = [vp, vp, vp]
+    L.uavx_get_env_levels.argtypes = [vp, vp, vp]
     L.uavx_reset.argtypes = [vp, vp, u64, vp, vp]
     L.uavx_step.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     L.uavx_step_k.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp]

@@ -109,16 +109,25 @@ class BatchedMultiUAVWorld2D(_Base):
     test_sac_multi.py:101-105)."""
 
     def __init__(self, num_envs, x_size=50.0, y_size=50.0, max_speed=10.0, max_acceleration=5.0, num_agents=4,
-                 collider_radius=1.0, d_sense=15, device=None, env_offset=0, seed=0):
+                 collider_radius=1.0, d_sense=15, device=None, env_offset=0, seed=0, num_bodies=0, body_speed=5.0,
+                 body_period=128, body_seed=0):
+        """num_agents = learning UAVs L (every tensor is [E, L, ...]).  num_bodies = scripted dynamic obstacles per env
+        (BASELINE configs[4]; an extension with no reference counterpart, see include/uavx.h uavx_set_body_rule): they are
+        further entries of the learners' neighbour model, stepped inside the kernel, and cost no action / obs / reward
+        traffic."""
         self._init_device(device)
-        if not (1 <= int(num_agents) <= _lib.MAX_AGENTS):
-            raise ValueError(f"uavx: num_agents must be in [1, {_lib.MAX_AGENTS}]")
+        if not (1 <= int(num_agents) and int(num_agents) + int(num_bodies) <= _lib.MAX_AGENTS and int(num_bodies) >= 0):
+            raise ValueError(f"uavx: need num_agents >= 1, num_bodies >= 0 and num_agents + num_bodies <= {_lib.MAX_AGENTS}")
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
+        self.num_bodies = int(num_bodies)
         self.tau = 0.02                                                                  # MUW:26
         self.env_offset, self.seed = int(env_offset), int(seed)
         cfg = self._adopt_world(x_size, y_size, max_speed, max_acceleration, collider_radius, d_sense)
         _lib.check(self._L.uavx_create(ctypes.byref(cfg), self.num_envs, self.env_offset, self._dev_index,
                                        ctypes.byref(self._h)))
+        if self.num_bodies:
+            self.set_body_rule(speed=body_speed, period=body_period, seed=body_seed)
+        self.levels = None
         E, N = self.num_envs, self.num_agents
         with torch.cuda.device(self.device):
             self._obs = [torch.zeros((E, N, _lib.OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
@@ -151,7 +160,7 @@ class BatchedMultiUAVWorld2D(_Base):
                                      dtype=np.float32)
         self.action_space = Box(-max_speed, max_speed, shape=(2,), dtype=np.float32)
         return _lib.Config(x_size, y_size, max_speed, max_acceleration, collider_radius, float(d_sense), self.tau,
-                           self.num_agents, 0)
+                           self.num_agents, self.num_bodies)
 
     def set_config(self, **world):
         """Curriculum hook: change any of x_size, y_size, max_speed, max_acceleration, collider_radius, d_sense for
@@ -165,9 +174,55 @@ class BatchedMultiUAVWorld2D(_Base):
             raise TypeError(f"uavx: unknown world parameter(s) {sorted(unknown)}")
         cur.update(world)
         cfg = _lib.Config(cur["x_size"], cur["y_size"], cur["max_speed"], cur["max_acceleration"],
-                          cur["collider_radius"], float(cur["d_sense"]), self.tau, self.num_agents, 0)
+                          cur["collider_radius"], float(cur["d_sense"]), self.tau, self.num_agents, self.num_bodies)
         _lib.check(self._L.uavx_set_config(self._h, ctypes.byref(cfg)), self._h)
         self._adopt_world(**cur)
+
+    # -- configs[4] extension: scripted bodies + randomized-reset curriculum (include/uavx.h) ------------------------
+    def set_body_rule(self, speed=5.0, period=128, seed=0):
+        """Cruise speed (m/s), waypoint period (env steps, a power of two) and Philox seed of the scripted bodies."""
+        rule = _lib.BodyRule(float(speed), int(period), 0, int(seed))
+        _lib.check(self._L.uavx_set_body_rule(self._h, ctypes.byref(rule)), self._h)
+        self.body_rule = dict(speed=float(speed), period=int(period), seed=int(seed))
+
+    def set_curriculum(self, levels, lo=-1, hi=-1):
+        """levels: list of dicts(x_size, y_size, collider_radius, d_sense[, n_active, b_active]) -- per-env worlds.  An
+        env takes its level when it is (re-)initialised (reset() or the auto-reset of step_ex): drawn uniformly in
+        [lo, hi] (the randomized-reset curriculum; move the window as training progresses), or, with lo < 0, the level
+        assigned by set_env_levels.  levels=None / [] removes the table."""
+        levels = list(levels or [])
+        arr = (_lib.Level * max(1, len(levels)))(*[
+            _lib.Level(float(l["x_size"]), float(l["y_size"]), float(l["collider_radius"]), float(l["d_sense"]),
+                       int(l.get("n_active", self.num_agents)), int(l.get("b_active", self.num_bodies))) for l in levels])
+        _lib.check(self._L.uavx_set_curriculum(self._h, arr, len(levels), int(lo), int(hi), self._stream()), self._h)
+        self.levels = levels or None
+
+    def set_level_window(self, lo, hi):
+        self.set_curriculum(self.levels, lo, hi)
+
+    def set_env_levels(self, levels):
+        """[E] uint8: the level each env takes at its NEXT reset (used while the random window is off, lo < 0)."""
+        t = torch.as_tensor(levels, device=self.device).to(torch.uint8).contiguous()
+        self._out(t, (self.num_envs,), torch.uint8, "levels")
+        _lib.check(self._L.uavx_set_env_levels(self._h, t.data_ptr(), self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def env_levels(self):
+        """[E] uint8: level in force in each env."""
+        t = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.uavx_get_env_levels(self._h, t.data_ptr(), self._stream()), self._h)
+        return t
+
+    def get_bodies(self):
+        """[E, B, 4] float32 {x, y, waypoint x, waypoint y}; a body switched off by its env's level sits at +inf."""
+        t = torch.empty((self.num_envs, self.num_bodies, 4), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.uavx_get_bodies(self._h, t.data_ptr(), self._stream()), self._h)
+        return t
+
+    def set_bodies(self, records):
+        t = torch.as_tensor(records, device=self.device).to(torch.float32).reshape(self.num_envs, self.num_bodies, 4).contiguous()
+        _lib.check(self._L.uavx_set_bodies(self._h, t.data_ptr(), self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()
 
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self):
@@ -271,7 +326,9 @@ class BatchedMultiUAVWorld2D(_Base):
           track_returns    accumulate episode return / evaluation score per env (:106,157)
         Auto-reset is next-step: an ended env keeps its terminal observation in this call's outputs and
         is re-initialised by the NEXT call instead of being stepped (that call's reset_mask[e] is True,
-        reward 0, done False).  Returns (obs, rew, done, info) with info["reset_mask"] [E] bool."""
+        reward 0, done False).  Returns (obs, rew, done, info) with [E] bool tensors info["reset_mask"],
+        info["ended"] (this call ended the env's episode) and info["truncated"] (it ended by the step cap alone: a
+        time-limit cut to bootstrap through, not a terminal state)."""
         fast = (out is None and type(actions) is torch.Tensor and actions.shape == self._act_shape
                 and actions.is_contiguous() and actions.device == self.device and actions.dtype in _TORCH_DT)
         if fast:
@@ -282,18 +339,25 @@ class BatchedMultiUAVWorld2D(_Base):
             self._flip ^= 1
             obs, rew, done, done_bool = self._obs[self._flip], self._rew, self._done, self._done_bool
             obs_ptr, rew_ptr, done_ptr = self._obs_ptr[self._flip], self._rew_ptr, self._done_ptr
-        else:
-            obs, rew, done = out
-            done = done.view(torch.uint8) if done.dtype == torch.bool else done
+        else:  # caller-owned output buffers (DeviceReplay): same shape / dtype / device / contiguity checks as step()
+            obs = self._out(out[0], self._obs[0].shape, torch.float32, "out[0]")
+            rew = self._out(out[1], self._rew.shape, torch.float32, "out[1]")
+            done = out[2].view(torch.uint8) if out[2].dtype == torch.bool else out[2]
+            done = self._out(done, self._done.shape, torch.uint8, "out[2]")
             done_bool = done.view(torch.bool)
             obs_ptr, rew_ptr, done_ptr = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+            if obs_ptr % 16:
+                raise ValueError("uavx: `out[0]` must be 16-byte aligned")
         if not hasattr(self, "_reset_mask"):
-            self._reset_mask = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+            self._reset_mask = torch.zeros((3, self.num_envs), dtype=torch.uint8, device=self.device)
             self._reset_mask_bool = self._reset_mask.view(torch.bool)
             self._ex_args = _lib.StepArgs()
-            self._ex_args.reset_mask = self._reset_mask.data_ptr()
+            self._ex_args.reset_mask = self._reset_mask[0].data_ptr()
+            self._ex_args.ended = self._reset_mask[1].data_ptr()
+            self._ex_args.truncated = self._reset_mask[2].data_ptr()
             self._ex_ref = ctypes.byref(self._ex_args)
-            self._ex_info = {"distance": 0, "reset_mask": self._reset_mask_bool}
+            self._ex_info = {"distance": 0, "reset_mask": self._reset_mask_bool[0], "ended": self._reset_mask_bool[1],
+                             "truncated": self._reset_mask_bool[2]}
         args = self._ex_args  # one struct reused across calls: only the fields that change are written
         args.actions, args.action_dtype = a.data_ptr(), code
         args.action_mode = _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN

