@@ -73,10 +73,10 @@ def polar_actions(gen, shape, vmax_norm, device):
     return torch.stack([v * torch.cos(th), v * torch.sin(th)], dim=-1).contiguous()
 
 
-def cpu_baseline(n_agents, budget_s=12.0):
+def cpu_baseline(n_agents, n_bodies=0, budget_s=12.0):
     """The CPU oracle (a C port of the reference's step, oracle/uavx_oracle.c) timed on this box's
-    host cores on a bounded sample of the same workload: 4 096 envs x n_agents, same reset seed and
-    action distribution."""
+    host cores on a bounded sample of the same workload: 4 096 envs x n_agents (+ n_bodies scripted bodies),
+    same reset seed and action distribution."""
     import oracle
     oracle.build()
     cores = min(os.cpu_count() or 1, 16)
@@ -87,7 +87,7 @@ def cpu_baseline(n_agents, budget_s=12.0):
     acts = np.stack([v * np.cos(a[..., 1] * np.pi), v * np.sin(a[..., 1] * np.pi)], axis=-1)
     out = {}
     for label, threads in (("1", 1), ("all", cores)):
-        orc = oracle.OracleMulti(num_envs=E, num_agents=n_agents, nthreads=threads)
+        orc = oracle.OracleMulti(num_envs=E, num_agents=n_agents, nthreads=threads, num_bodies=n_bodies)
         orc.reset_philox(0)
         for k in range(3):
             orc.step(acts[k % 8])
@@ -109,7 +109,8 @@ def cpu_baseline(n_agents, budget_s=12.0):
     except OSError:
         pass
     res = dict(value=out["all"], unit="env-steps/s", cores=cores, kind="port", cpu_model=model, host_cpus=os.cpu_count(),
-               sample=f"{E} envs x {n_agents} UAVs, oracle/uavx_oracle.c with OpenMP over envs on {cores} threads, ~{budget_s / 2:.0f} s",
+               sample=f"{E} envs x {n_agents} UAVs" + (f" + {n_bodies} scripted bodies" if n_bodies else "") +
+                      f", oracle/uavx_oracle.c with OpenMP over envs on {cores} threads, ~{budget_s / 2:.0f} s",
                single_thread_value=out["1"])
     # the unmodified Python reference cannot travel to the GPU box: its timing is taken in the build container by
     # tools/time_reference.py and attached here with its provenance
@@ -119,7 +120,7 @@ def cpu_baseline(n_agents, budget_s=12.0):
         try:
             ref = json.load(open(refs[-1]))
             row = next((r for r in ref["rows"] if r["world"] == "MultiUAVWorld2D" and r["num_agents"] == n_agents), None)
-            if row:
+            if row and not n_bodies:
                 res["reference_python"] = dict(value=row["env_steps_per_s"], unit="env-steps/s", cores=1,
                                                provenance=f"{os.path.basename(refs[-1])}: {ref['provenance']}")
         except Exception:
@@ -417,7 +418,7 @@ def main():
             torch.cuda.empty_cache()
             line["roofline_large"] = large_batch_point(N, device, gen, bodies=B)
         if world == 1 and not args.no_cpu_baseline and args.world == "multi":
-            line["cpu_baseline"] = cpu_baseline(N)
+            line["cpu_baseline"] = cpu_baseline(N, B)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     env.close()

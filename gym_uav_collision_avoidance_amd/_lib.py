@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libuavx.so")
+LIB_PATH = os.environ.get("UAVX_LIB") or os.path.join(CSRC, "libuavx.so")  # UAVX_LIB: A/B builds of the same library (tools/)
 
 OBS_DIM = 10
 UW_OBS_DIM = 4

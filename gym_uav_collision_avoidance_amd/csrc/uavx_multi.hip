@@ -681,9 +681,13 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                 const float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
                 clash = phase ? too_close(sq2r, qx, qy, c.sx, c.sy) : false;                       // MUW:146
 #pragma unroll 1
-                for (int j = 0; j < m.i; j++) {
-                    const float4 o = row[j];
-                    clash = clash || too_close(sq2r, phase ? o.z : o.x, phase ? o.w : o.y, qx, qy);  // MUW:135,151
+                for (int j0 = 0; j0 < m.i; j0 += 4) {  // four rows per trip (LDS round trips bound this loop)
+                    float4 o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) o[u] = row[min(j0 + u, m.i - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        clash = clash || too_close(sq2r, phase ? o[u].z : o[u].x, phase ? o[u].w : o[u].y, qx, qy);  // MUW:135,151
                 }
             }
             const unsigned long long bits = __ballot(clash);
@@ -717,15 +721,20 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
             for (;;) {
                 bool clash = false;
                 if (on) {
+                    // against the learners' accepted start points (rows 0..nl-1) and the lower-indexed bodies (rows
+                    // N..N+b-1), four rows per trip: the loop is bound by LDS round trips, not by arithmetic, and the
+                    // slowest resetting wave of a launch is what the whole launch waits for
+                    const int cnt = nl + b;
 #pragma unroll 1
-                    for (int j = 0; j < nl; j++) {          // the learners' accepted start points
-                        const float4 o = row[j];
-                        clash = clash || too_close(sq2r, o.x, o.y, qx, qy);
-                    }
-#pragma unroll 1
-                    for (int j = 0; j < b; j++) {           // lower-indexed bodies
-                        const float4 o = row[N + j];
-                        clash = clash || too_close(sq2r, o.x, o.y, qx, qy);
+                    for (int j0 = 0; j0 < cnt; j0 += 4) {
+                        float4 o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int j = min(j0 + u, cnt - 1);
+                            o[u] = row[j < nl ? j : N + (j - nl)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) clash = clash || too_close(sq2r, o[u].x, o[u].y, qx, qy);
                     }
                 }
                 const unsigned long long bits = __ballot(clash);

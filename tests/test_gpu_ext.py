@@ -89,12 +89,15 @@ def test_config5_combined_vs_oracle(amd, oracle_mod):
     actions, all-done auto-reset and a step cap, observations written zero-copy into DeviceReplay."""
     import torch
     from gym_uav_collision_avoidance_amd.replay import DeviceReplay
-    E, L, B, cap = 1536, 8, 16, 48
-    kw = dict(num_agents=L, num_bodies=B, body_speed=4.0, body_period=16, body_seed=3)
+    E, L, B, cap = 1024, 8, 16, 140
+    small = [dict(x_size=14.0, y_size=14.0, collider_radius=0.3, d_sense=6.0, n_active=2, b_active=3),
+             dict(x_size=18.0, y_size=16.0, collider_radius=0.4, d_sense=8.0, n_active=4, b_active=8),
+             dict(x_size=24.0, y_size=24.0, collider_radius=0.5, d_sense=10.0, n_active=8, b_active=16)]
+    kw = dict(num_agents=L, num_bodies=B, body_speed=2.0, body_period=16, body_seed=3)
     env = amd.BatchedMultiUAVWorld2D(E, seed=21, env_offset=7, **kw)
     orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
-    env.set_curriculum(LEVELS, lo=0, hi=1)
-    orc.set_curriculum(LEVELS, lo=0, hi=1)
+    env.set_curriculum(small, lo=0, hi=1)
+    orc.set_curriculum(small, lo=0, hi=1)
     mem = DeviceReplay(env, horizon=24)
     mem.begin(env.reset())
     orc.reset_philox(21, env_offset=7)
@@ -102,8 +105,8 @@ def test_config5_combined_vs_oracle(amd, oracle_mod):
     assert set(np.unique(orc.level)) == {0, 1}
     rng = np.random.default_rng(8)
     n_reset = n_trunc = n_term = 0
-    for t in range(150):
-        if t == 60:   # the curriculum window moves on
+    for t in range(330):
+        if t == 150:   # the curriculum window moves on
             env.set_level_window(1, 2)
             orc.set_level_window(1, 2)
         a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
@@ -127,7 +130,6 @@ def test_config5_combined_vs_oracle(amd, oracle_mod):
         assert obs_g.data_ptr() == mem.obs[(t + 1) % 25].data_ptr()           # zero-copy: the kernel wrote into the ring
         n_reset += int(rm_o.sum()); n_trunc += int(tr_o.sum()); n_term += int((en_o & ~tr_o).sum())
     assert n_reset > E and n_trunc > 0 and n_term > 0, (n_reset, n_trunc, n_term)
-    assert set(np.unique(orc.level)) <= {1, 2} or True
     stats = {k: _np(v) for k, v in env.episode_stats().items()}
     np.testing.assert_array_equal(stats["episodes"], orc.fin_counts[:, 0])
     np.testing.assert_array_equal(stats["reach"], orc.fin_counts[:, 2])
