@@ -27,7 +27,7 @@
 //   per wave:  wave_steps[W] (one no-return atomic per launch; env.steps = wave_steps - env_rec.x)
 //   per env:   reach[E] / coll[E] (atomics on the rare events), env_rec[E] (16 B: steps base, episode index,
 //              running returns; touched by reset / step_ex only), episode statistics (fin_*).
-// One wavefront per workgroup (kBlock = 64).
+// One wavefront per workgroup, except on the runtime-N path where pick_group_waves() finds that several pack better.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -123,30 +123,34 @@ struct StepExtra {
 };
 
 struct LaneMap {
-    int lane, wib;   // lane in wave, wave in block
+    int lane, wib;   // thread in its workgroup (the lane when the workgroup is one wavefront); unused
     int i, base;     // agent index in its env, first lane of the env's group
-    int rbase, nslots;  // first LDS neighbour row of the env, rows per env (= base, N unless the env has scripted bodies)
+    int rbase, nslots;  // first LDS neighbour row of the env, rows per env (N unless the env has scripted bodies)
+    int g;              // env index within the workgroup
     bool active;
     uint32_t e, a;   // env, agent slot (E*N < 2^26, checked by uavx_create)
-    uint32_t a0;     // first agent slot of this wave
-    uint32_t wave;   // global wavefront index (= index into wave_steps)
-    int cnt;         // active agent slots in this wave: lanes [0, cnt), slots [a0, a0 + cnt)
+    uint32_t a0;     // first agent slot of this workgroup
+    uint32_t wave;   // workgroup index (= index into wave_steps)
+    int cnt;         // active agent slots in this workgroup: threads [0, cnt), slots [a0, a0 + cnt)
 };
 
-template <int NT, bool EXT = false>
+// Work mapping of one launch: a workgroup of W wavefronts holds epw = floor(64 W / N) whole envs, one thread per agent,
+// packed from thread 0 (so agent slot = a0 + thread id).  W = 1 everywhere except for agent counts that would leave
+// many lanes of a single wavefront idle (N = 24: 48 of 64; three wavefronts hold 8 envs with none idle).
+template <int NT, bool EXT = false, int W = 1>
 __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     LaneMap m;
     const int N = NT ? NT : p.N;
     const int epw = NT ? (kWave / (NT ? NT : 1)) : p.epw;
-    m.lane = threadIdx.x & (kWave - 1);
-    m.wib = threadIdx.x >> 6;
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + m.wib;
+    m.lane = threadIdx.x;            // thread in its workgroup (= lane for W == 1)
+    m.wib = 0;
+    const uint32_t wave = blockIdx.x;   // workgroup index (= wavefront index for W == 1)
     int g;
     if (NT) {
         g = m.lane / (NT ? NT : 1);
         m.i = m.lane % (NT ? NT : 1);
     } else {
-        g = (m.lane * p.magic) >> 16;  // floor(lane / N) for lane < 64
+        g = (m.lane * p.magic) >> 16;  // floor(thread / N) for thread < 256
         m.i = m.lane - g * N;
     }
     m.wave = wave;
@@ -155,11 +159,12 @@ __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     const uint32_t envs_here = e0 < E ? min(E - e0, (uint32_t)epw) : 0u;
     m.e = e0 + g;
     m.active = (uint32_t)g < envs_here;
-    m.base = m.active ? g * N : 0;  // idle lanes still execute the LDS scan: keep it in bounds
+    m.base = m.active ? (g * N) & (kWave - 1) : 0;  // first lane of the env's group in its wavefront (W == 1: ballot shifts)
+    m.g = m.active ? g : 0;
     m.nslots = EXT ? p.nslots : N;
-    m.rbase = EXT ? (m.active ? g * p.nslots : 0) : m.base;
+    m.rbase = m.active ? g * m.nslots : 0;  // idle lanes still execute the LDS scan: keep it in bounds
     m.a0 = e0 * N;
-    m.a = m.a0 + m.lane;            // whole envs are packed from lane 0: slot = a0 + lane
+    m.a = m.a0 + m.lane;            // whole envs are packed from thread 0: slot = a0 + thread
     m.cnt = (int)envs_here * N;
     return m;
 }
@@ -171,13 +176,27 @@ struct AgentRegs {
     double vx, vy;
 };
 
-template <bool EXT>
+// LDS of one workgroup (W wavefronts; W > 1 only on the runtime-N path, see pick_group_waves()).
+template <bool EXT, int W = 1>
 struct LdsT {
-    static constexpr int kRows = EXT ? kExtSlots : kWave;
-    float4 pos[kWavesPerBlock][kRows];            // {old.x, old.y, new.x, new.y} per neighbour slot
-    float theta[kWavesPerBlock][kRows];           // heading atan2(vy, vx)
-    float obs[kWavesPerBlock][kWave * UAVX_OBS_DIM];
+    static constexpr int kW = W;
+    static constexpr int kRows = EXT ? kExtSlots : kWave * W;
+    float4 pos[kRows];            // {old.x, old.y, new.x, new.y} per neighbour slot
+    float theta[kRows];           // heading atan2(vy, vx)
+    float obs[kWave * W * UAVX_OBS_DIM];
 };
+// All cross-agent traffic of an env stays inside its workgroup.  With one wavefront per workgroup a compiler-level
+// ordering point is enough (wave_lds_sync); an env that spans two wavefronts needs the workgroup barrier.
+template <int W>
+__device__ __forceinline__ void group_sync() {
+    if (W == 1) wave_lds_sync();
+    else __syncthreads();
+}
+template <int W>
+__device__ __forceinline__ bool group_any(bool v) {   // same answer in every thread of the workgroup
+    if (W == 1) return __ballot(v) != 0ull;
+    return __syncthreads_or(v ? 1 : 0) != 0;
+}
 using Lds = LdsT<false>;
 
 // World limits of this lane's env: kernel arguments, or (EXT) the level its flags word names -- two 16-byte loads from a
@@ -247,7 +266,7 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const WorldLims &w, const
     r.d1 = r.d2 = INFINITY;
     r.j1 = r.j2 = -1;
     r.step_sq_min = INFINITY;
-    const float4 *row = &lds.pos[m.wib][m.rbase];
+    const float4 *row = &lds.pos[m.rbase];
     // Branch-free: out-of-range agents enter the insertion with distance +inf, which never displaces.
     auto visit = [&](int j, float4 q) {
         const float dxn = q.z - nx, dyn = q.w - ny;  // target_agent.location - self.location (AG:51)
@@ -314,10 +333,10 @@ __device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneM
     if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);
     const int N = NT ? NT : m.nslots;
     if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);  // <= 4 others: nothing to save
-    const float4 *row = &lds.pos[m.wib][m.rbase];
+    const float4 *row = &lds.pos[m.rbase];
     uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
     float step_min = INFINITY;
-    auto visit = [&](int j, float4 q) {
+    auto visit = [&](int j, bool below, float4 q) {   // below: j < m.i
         const float dxn = q.z - nx, dyn = q.w - ny;
         const float ax = dxn * dxn, ay = dyn * dyn;
         const float sn = ax + ay;
@@ -325,7 +344,7 @@ __device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneM
             const float dxo = q.x - nx, dyo = q.y - ny;
             const float bx = dxo * dxo, by = dyo * dyo;
             const float so = bx + by;
-            step_min = fminf(step_min, (j < m.i) ? sn : so);  // fminf drops NaN; the d_sense test follows the loop
+            step_min = fminf(step_min, below ? sn : so);  // fminf drops NaN; the d_sense test follows the loop
         }
         const uint32_t key = (__float_as_uint(sn) & ~63u) | (uint32_t)j;
         k3 = med3_u32(k2, k3, key);
@@ -342,19 +361,23 @@ __device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneM
             q[k] = row[js[k]];
         }
 #pragma unroll
-        for (int k = 0; k < NT - 1; k++) visit(js[k], q[k]);
+        for (int k = 0; k < NT - 1; k++) visit(js[k], js[k] < m.i, q[k]);
     } else {
-        // two neighbours per trip, written out (inline asm is convergent in HIP, which rules out the unroll pragma)
+        // two neighbours per trip, written out (inline asm is convergent in HIP, which rules out the unroll pragma);
+        // the k-th other agent is j = k (below me: already moved) or k + 1 (above me: not yet) -- ONE compare gives both
+        // the index and the Gauss-Seidel select
         int k = 0;
         for (; k + 1 < N - 1; k += 2) {
-            const int ja = k + (k >= m.i ? 1 : 0), jb = k + 1 + (k + 1 >= m.i ? 1 : 0);
+            const bool la = k < m.i, lb = k + 1 < m.i;
+            const int ja = la ? k : k + 1, jb = lb ? k + 1 : k + 2;
             const float4 qa = row[ja], qb = row[jb];
-            visit(ja, qa);
-            visit(jb, qb);
+            visit(ja, la, qa);
+            visit(jb, lb, qb);
         }
         if (k < N - 1) {
-            const int j = k + (k >= m.i ? 1 : 0);
-            visit(j, row[j]);
+            const bool la = k < m.i;
+            const int j = la ? k : k + 1;
+            visit(j, la, row[j]);
         }
     }
     // N > 5: at least five neighbours were visited, so k1..k3 are real keys (their low bits are agent indices)
@@ -388,8 +411,8 @@ __device__ __forceinline__ void assemble_obs(const MultiParams &p, const WorldLi
     // absent neighbour: d=1, bearing (pi + theta) - theta wraps to +-pi -> +-1 (one point on the circle), heading 0
     const bool has1 = nb.j1 >= 0, has2 = nb.j2 >= 0;
     const int i1 = m.rbase + (has1 ? nb.j1 : 0), i2 = m.rbase + (has2 ? nb.j2 : 0);
-    const float4 q1 = lds.pos[m.wib][i1], q2 = lds.pos[m.wib][i2];
-    const float t1 = lds.theta[m.wib][i1], t2 = lds.theta[m.wib][i2];
+    const float4 q1 = lds.pos[i1], q2 = lds.pos[i2];
+    const float t1 = lds.theta[i1], t2 = lds.theta[i2];
     const float b1 = wrap_pi(atan2_fast(q1.w - ny, q1.z - nx) - theta) * kInvPi;  // MUW:78-81
     const float b2 = wrap_pi(atan2_fast(q2.w - ny, q2.z - nx) - theta) * kInvPi;  // MUW:88-91
     const float h1 = wrap_pi(t1 - theta) * kInvPi;                                // MUW:82-85
@@ -409,30 +432,31 @@ __device__ __forceinline__ void assemble_obs(const MultiParams &p, const WorldLi
 template <int NT, class LDS>
 __device__ __forceinline__ void store_obs_block(const MultiParams &p, const LaneMap &m, LDS &lds, const float o[10],
                                                 float *obs_out) {
-    float *stage = lds.obs[m.wib];
+    constexpr int T = kWave * LDS::kW;
+    float *stage = lds.obs;
     if (m.active) {
         float2 *dst = reinterpret_cast<float2 *>(stage + m.lane * UAVX_OBS_DIM);
 #pragma unroll
         for (int k = 0; k < 5; k++) dst[k] = make_float2(o[2 * k], o[2 * k + 1]);
     }
-    wave_lds_sync();
+    group_sync<LDS::kW>();
     const int nfloat = m.cnt * UAVX_OBS_DIM;
     const rsrc_t r = make_rsrc(obs_out, (uint32_t)p.E * (uint32_t)p.N * (UAVX_OBS_DIM * 4u));
-    const uint32_t gbase = m.a0 * (UAVX_OBS_DIM * 4u);  // byte offset of the wave's block
-    if (NT != 0 && NT % 2 == 0) {
+    const uint32_t gbase = m.a0 * (UAVX_OBS_DIM * 4u);  // byte offset of the workgroup's block
+    if (NT ? (NT % 2 == 0) : ((p.N & 1) == 0)) {   // uniform: even N => 16-byte aligned block of whole float4
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const int f = (k * kWave + m.lane) * 4;
+            const int f = (k * T + m.lane) * 4;
             if (f < nfloat) store16_wt(r, gbase + f * 4u, *reinterpret_cast<const float4 *>(stage + f));
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            const int f = (k * kWave + m.lane) * 2;
+            const int f = (k * T + m.lane) * 2;
             if (f < nfloat) store8_wt(r, gbase + f * 4u, *reinterpret_cast<const float2 *>(stage + f));
         }
     }
-    wave_lds_sync();
+    group_sync<LDS::kW>();
 }
 
 // configs[4] extension: the scripted bodies of this lane's env (include/uavx.h, uavx_set_body_rule).  Body b is handled
@@ -454,7 +478,7 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
         const int row = m.rbase + L + (valid ? b : 0);
         const uint32_t gi = m.e * (uint32_t)p.B + (uint32_t)b;
         float4 r = make_float4(INFINITY, INFINITY, 0.f, 0.f);
-        if (on) r = from_lds ? lds.pos[m.wib][row] : p.body[gi];
+        if (on) r = from_lds ? lds.pos[row] : p.body[gi];
         const float ox = r.x, oy = r.y;
         if (MOVE && on && !frozen) {
             if (steps != 0u && (steps & (uint32_t)p.body_pmask) == 0u) {  // a new waypoint every `period` steps
@@ -474,8 +498,8 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
             }
         }
         if (valid) {
-            lds.pos[m.wib][row] = on ? make_float4(ox, oy, r.x, r.y) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-            lds.theta[m.wib][row] = atan2_fast(r.w - r.y, r.z - r.x);   // heading: towards the waypoint
+            lds.pos[row] = on ? make_float4(ox, oy, r.x, r.y) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            lds.theta[row] = atan2_fast(r.w - r.y, r.z - r.x);   // heading: towards the waypoint
         }
         if (MOVE && on && !frozen) p.body[gi] = r;
     }
@@ -510,10 +534,10 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
 
     if (EXT && p.B > 0) stage_bodies<true>(p, m, lds, s.flags, bodies_from_lds, frozen, env_steps, ep_draw);
     if (m.active) {
-        lds.pos[m.wib][m.rbase + m.i] = make_float4(ox, oy, s.x, s.y);   // a parked learner sits at +inf
-        lds.theta[m.wib][m.rbase + m.i] = theta;
+        lds.pos[m.rbase + m.i] = make_float4(ox, oy, s.x, s.y);   // a parked learner sits at +inf
+        lds.theta[m.rbase + m.i] = theta;
     }
-    wave_lds_sync();
+    group_sync<LDS::kW>();
     const Neigh nb = scan_neighbours<NT, true>(w, m, lds, s.x, s.y);
 
     // reward shaping, MUW:188-195 (float32, reciprocals instead of divisions; |error| << 1e-5)
@@ -578,19 +602,20 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 }
 
 // One env step per launch (the RL loop's shape: the policy runs between two launches).
-template <int NT, bool ACT64, bool EXT>
-__global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
-                                                      float *__restrict__ obs_out, float *__restrict__ rew_out,
-                                                      uint8_t *__restrict__ done_out) {
-    __shared__ LdsT<EXT> lds;
-    const LaneMap m = lane_map<NT, EXT>(p);
+template <int NT, bool ACT64, bool EXT, int W>
+__global__ __launch_bounds__(kWave * W) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+                                                         float *__restrict__ obs_out, float *__restrict__ rew_out,
+                                                         uint8_t *__restrict__ done_out) {
+    using LDS = LdsT<EXT, W>;
+    __shared__ LDS lds;
+    const LaneMap m = lane_map<NT, EXT, W>(p);
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
     uint4 rec = make_uint4(0, 0, 0, 0);
     uint32_t wave_count = 0;
     if (EXT) {  // the bodies' waypoint schedule runs on the env's step count and episode index
         if (m.active) rec = p.env_rec[m.e];
-        wave_count = p.wave_steps[__builtin_amdgcn_readfirstlane(m.wave)];
+        wave_count = p.wave_steps[blockIdx.x];
     }
     if (m.active) {
         load_agent(p, m.a, s);
@@ -613,6 +638,27 @@ __global__ __launch_bounds__(kBlock) void step_kernel(MultiParams p, const void 
         }
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
+}
+
+// One round of the accept/reject chain: does any agent of the workgroup clash, and which is the lowest-indexed clashing
+// agent of MY env?  One wavefront per workgroup: a ballot.  Several: an LDS min per env (scratch in the obs tile, which is
+// only used at the very end of a launch) and a workgroup-wide OR.  Returns false when nobody clashes (uniform).
+template <class LDS>
+__device__ __forceinline__ bool lowest_clash(const LaneMap &m, LDS &lds, unsigned long long group, bool clash, int &low) {
+    if (LDS::kW == 1) {
+        const unsigned long long bits = __ballot(clash);
+        const unsigned long long mine = (bits >> m.base) & group;     // clashing agents of my env
+        low = mine ? (int)__builtin_ctzll(mine) : 64;
+        return bits != 0ull;
+    } else {
+        int *slot = reinterpret_cast<int *>(lds.obs) + m.g;
+        if (m.i == 0) *slot = 64;
+        __syncthreads();
+        if (clash) atomicMin(slot, m.i);
+        const bool any = __syncthreads_or(clash ? 1 : 0) != 0;
+        low = *slot;
+        return any;
+    }
 }
 
 // ||a - b|| <= float32(2R) on the squared distance (exact: sqrtf is monotone, limit from sq_limit_le)
@@ -641,7 +687,7 @@ template <int NT, bool EXT, class LDS>
 __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, LDS &lds, bool go,
                                                 uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s) {
     const int N = NT ? NT : p.N;
-    float4 *row = &lds.pos[m.wib][m.rbase];
+    float4 *row = &lds.pos[m.rbase];
     const uint64_t ge = (uint64_t)p.env_offset + m.e;
     const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     double lox = p.lox, loy = p.loy, hix = p.hix, hiy = p.hiy;
@@ -670,7 +716,7 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
         c = reset_candidates(ge, m.i, 0u, episode, k0, k1, lox, loy, hix, hiy);
         row[m.i] = make_float4(c.sx, c.sy, c.tx, c.ty);
     }
-    wave_lds_sync();
+    group_sync<LDS::kW>();
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {  // 0: start points MUW:126-137, 1: targets MUW:140-153
         uint32_t attempt = 0;
@@ -690,17 +736,16 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                         clash = clash || too_close(sq2r, phase ? o[u].z : o[u].x, phase ? o[u].w : o[u].y, qx, qy);  // MUW:135,151
                 }
             }
-            const unsigned long long bits = __ballot(clash);
-            if (bits == 0ull) break;
-            const unsigned long long mine = (bits >> m.base) & group;     // clashing agents of my env
-            const bool redraw = gl && mine != 0ull && m.i == (int)__builtin_ctzll(mine);
-            wave_lds_sync();
+            int low;   // lowest-indexed clashing agent of my env (>= N: none)
+            if (!lowest_clash<LDS>(m, lds, group, clash, low)) break;
+            const bool redraw = gl && m.i == low;
+            group_sync<LDS::kW>();
             if (redraw) {  // the lowest-indexed clashing agent takes its next candidate
                 const ResetCandidates r = reset_candidates(ge, m.i, ++attempt, episode, k0, k1, lox, loy, hix, hiy);
                 if (phase) { c.tx = r.tx; c.ty = r.ty; row[m.i].z = c.tx; row[m.i].w = c.ty; }
                 else { c.sx = r.sx; c.sy = r.sy; row[m.i].x = c.sx; row[m.i].y = c.sy; }
             }
-            wave_lds_sync();
+            group_sync<LDS::kW>();
         }
     }
     if (EXT) {
@@ -716,7 +761,7 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                 qx = r.sx; qy = r.sy;
                 row[slot].x = qx; row[slot].y = qy;
             }
-            wave_lds_sync();
+            group_sync<LDS::kW>();
 #pragma unroll 1
             for (;;) {
                 bool clash = false;
@@ -737,17 +782,16 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                         for (int u = 0; u < 4; u++) clash = clash || too_close(sq2r, o[u].x, o[u].y, qx, qy);
                     }
                 }
-                const unsigned long long bits = __ballot(clash);
-                if (bits == 0ull) break;
-                const unsigned long long mine = (bits >> m.base) & group;
-                const bool redraw = on && mine != 0ull && m.i == (int)__builtin_ctzll(mine);
-                wave_lds_sync();
+                int low;
+                if (!lowest_clash<LDS>(m, lds, group, clash, low)) break;
+                const bool redraw = on && m.i == low;
+                group_sync<LDS::kW>();
                 if (redraw) {
                     const ResetCandidates r = reset_candidates(ge, (uint32_t)slot, ++attempt, episode, k0, k1, lox, loy, hix, hiy);
                     qx = r.sx; qy = r.sy;
                     row[slot].x = qx; row[slot].y = qy;
                 }
-                wave_lds_sync();
+                group_sync<LDS::kW>();
             }
             if (go && b < p.B) {
                 float4 rec = make_float4(INFINITY, INFINITY, 0.f, 0.f);    // a body that does not take part
@@ -761,7 +805,7 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
             }
         }
     }
-    wave_lds_sync();
+    group_sync<LDS::kW>();
     if (go) {
         s.x = c.sx; s.y = c.sy; s.tx = c.tx; s.ty = c.ty;
         s.init_d = s.prev_d = norm32(c.tx - c.sx, c.ty - c.sy);  // MUW:154-155
@@ -820,13 +864,14 @@ __device__ unsigned int g_stamp_n;
 
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
 // episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
-template <int NT, bool ACT64, bool EXT>
-__global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
-                                                         int evaluate, float *__restrict__ obs_out,
-                                                         float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
-    __shared__ LdsT<EXT> lds;
+template <int NT, bool ACT64, bool EXT, int W>
+__global__ __launch_bounds__(kWave * W) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+                                                            int evaluate, float *__restrict__ obs_out,
+                                                            float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
+    using LDS = LdsT<EXT, W>;
+    __shared__ LDS lds;
     const int N = NT ? NT : p.N;
-    const LaneMap m = lane_map<NT, EXT>(p);
+    const LaneMap m = lane_map<NT, EXT, W>(p);
 #ifdef UAVX_STAMPS
     unsigned long long stamps[8] = {};
     const bool stamp_on = true;
@@ -839,7 +884,7 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
     // state loads of the launch-wide read burst.  The wave's step counter comes through the scalar cache.
     uint4 rec = make_uint4(0, 0, 0, 0);
     if (m.active) rec = p.env_rec[m.e];
-    const uint32_t wave_count = p.wave_steps[__builtin_amdgcn_readfirstlane(m.wave)];
+    const uint32_t wave_count = p.wave_steps[blockIdx.x];
     __builtin_amdgcn_sched_barrier(0);
     AgentRegs ld = {};
     if (m.active) {
@@ -855,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
     EpisodeFold fold = {};
     const uint32_t ended_steps = steps_v;
     const float2 ended_run = run;
-    const bool wave_resets = __ballot(do_reset) != 0ull;
+    const bool wave_resets = group_any<W>(do_reset);   // uniform over the workgroup
     STAMP(1);
     if (wave_resets) {  // wave-uniform: at least one env of this wave starts a new episode
         // A wave that re-initialises an env has a few hundred more instructions to issue than its three SIMD
@@ -885,12 +930,23 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
                         (episode - (do_reset ? 0u : 1u)) & ~kRecEnded, do_reset);
     STAMP(4);
     // episode end test for the NEXT call (test_sac_multi.py:67,112,116)
-    const unsigned long long done_bits = __ballot(dn != 0);
-    const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-    const bool all_done = ((done_bits >> m.base) & group) == group;
+    bool all_done;
+    if (W == 1) {
+        const unsigned long long done_bits = __ballot(dn != 0);
+        const unsigned long long group = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+        all_done = ((done_bits >> m.base) & group) == group;
+    } else {  // the env may span two wavefronts: count its done agents in LDS (obs tile scratch, free until the final store)
+        int *cnt = reinterpret_cast<int *>(lds.obs) + m.g;
+        if (m.i == 0) *cnt = 0;
+        __syncthreads();
+        if (m.active && dn != 0) atomicAdd(cnt, 1);
+        __syncthreads();
+        all_done = *cnt == N;
+        __syncthreads();
+    }
     if (x.track_returns) {
-        if (m.active) lds.theta[m.wib][m.rbase + m.i] = do_reset ? 0.f : rew * (1.0f - (float)dn);  // test_sac_multi.py:157
-        wave_lds_sync();
+        if (m.active) lds.theta[m.rbase + m.i] = do_reset ? 0.f : rew * (1.0f - (float)dn);  // test_sac_multi.py:157
+        group_sync<LDS::kW>();
     }
     if (m.active) {
         if (!(EXT && (s.flags & kFlagInactive))) store_agent(p, m.a, s, flags_in);
@@ -918,7 +974,7 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
             out.y = (out.y & ~kRecEnded) | (ended ? kRecEnded : 0u);
             if (x.track_returns) {
                 float score = 0.f;
-                for (int j = 0; j < N; j++) score += lds.theta[m.wib][m.rbase + j];
+                for (int j = 0; j < N; j++) score += lds.theta[m.rbase + j];
                 run.x += do_reset ? 0.f : rew;               // test_sac_multi.py:106 score += rewards[0]
                 run.y += score;
             }
@@ -942,13 +998,14 @@ __global__ __launch_bounds__(kBlock) void step_ex_kernel(MultiParams p, StepExtr
 
 // K consecutive steps per launch from an action tape (open-loop rollouts): agent state stays in
 // registers, only actions are read and obs/rew/done written per step.
-template <int NT, bool ACT64>
-__global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
-                                                        int K, int tape_out, float *__restrict__ obs_out,
-                                                        float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
-    __shared__ Lds lds;
+template <int NT, bool ACT64, int W>
+__global__ __launch_bounds__(kWave * W) void step_k_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+                                                           int K, int tape_out, float *__restrict__ obs_out,
+                                                           float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
+    using LDS = LdsT<false, W>;
+    __shared__ LDS lds;
     const int N = NT ? NT : p.N;
-    const LaneMap m = lane_map<NT>(p);
+    const LaneMap m = lane_map<NT, false, W>(p);
     AgentRegs s = {};
     if (m.active) load_agent(p, m.a, s);
     const uint32_t flags_in = s.flags;
@@ -971,7 +1028,7 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
             }
             store_obs_block<NT>(p, m, lds, o, obs_out + off * UAVX_OBS_DIM);
         } else {
-            wave_lds_sync();
+            group_sync<LDS::kW>();
         }
     }
     if (m.active) {
@@ -982,10 +1039,11 @@ __global__ __launch_bounds__(kBlock) void step_k_kernel(MultiParams p, const voi
     }
 }
 
-template <int NT, bool EXT>
-__global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *__restrict__ obs_out) {
-    __shared__ LdsT<EXT> lds;
-    const LaneMap m = lane_map<NT, EXT>(p);
+template <int NT, bool EXT, int W>
+__global__ __launch_bounds__(kWave * W) void observe_kernel(MultiParams p, float *__restrict__ obs_out) {
+    using LDS = LdsT<EXT, W>;
+    __shared__ LDS lds;
+    const LaneMap m = lane_map<NT, EXT, W>(p);
     AgentRegs s = {};
     if (m.active) load_agent(p, m.a, s);
     const WorldLims w = world_lims<EXT>(p, s.flags);
@@ -995,10 +1053,10 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *_
     const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);
     if (EXT && p.B > 0) stage_bodies<false>(p, m, lds, s.flags, false, true, 0u, 0u);
     if (m.active) {
-        lds.pos[m.wib][m.rbase + m.i] = make_float4(s.x, s.y, s.x, s.y);
-        lds.theta[m.wib][m.rbase + m.i] = theta;
+        lds.pos[m.rbase + m.i] = make_float4(s.x, s.y, s.x, s.y);
+        lds.theta[m.rbase + m.i] = theta;
     }
-    wave_lds_sync();
+    group_sync<LDS::kW>();
     const Neigh nb = scan_neighbours<NT, false>(w, m, lds, s.x, s.y);
     const float speed = __builtin_amdgcn_sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
     float o[10];
@@ -1011,12 +1069,13 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(MultiParams p, float *_
 }
 
 // MUW:116-168 for the masked envs, same lane-per-agent mapping and sampler as the in-step auto-reset.
-template <int NT, bool EXT>
-__global__ __launch_bounds__(kBlock) void reset_kernel(MultiParams p, const uint8_t *__restrict__ mask, uint64_t seed) {
-    __shared__ LdsT<EXT> lds;
-    const LaneMap m = lane_map<NT, EXT>(p);
+template <int NT, bool EXT, int W>
+__global__ __launch_bounds__(kWave * W) void reset_kernel(MultiParams p, const uint8_t *__restrict__ mask, uint64_t seed) {
+    using LDS = LdsT<EXT, W>;
+    __shared__ LDS lds;
+    const LaneMap m = lane_map<NT, EXT, W>(p);
     const bool go = m.active && (!mask || mask[m.e] != 0);
-    if (__ballot(go) == 0ull) return;
+    if (!group_any<W>(go)) return;
     AgentRegs s = {};
     uint4 rec = make_uint4(0, 0, 0, 0);
     if (go) rec = p.env_rec[m.e];
@@ -1166,6 +1225,7 @@ struct uavx_handle {
     WideLimits wl = {};
     void *wide_slab = nullptr;
     // configs[4] extension: scripted bodies and / or an installed curriculum select the EXT kernel variants
+    int gw = 1;  // wavefronts per workgroup of the step / reset / observe launches (pick_group_waves)
     bool ext = false;
     uavx_body_rule rule = {5.0, 128, 0, 0};
     LevelTable levels = {};
@@ -1236,30 +1296,84 @@ float sq_limit_le(float lim) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-template <int NT, bool EXT>
-void launch_step_nt(uavx_handle *h, dim3 grid, hipStream_t st, const void *actions, int action_dtype, int evaluate, int K,
-                    int tape_out, float *obs, float *rew, uint8_t *done) {
-    const dim3 blk(kBlock);
-    if (K == 1) {
-        if (action_dtype == UAVX_F64)
-            hipLaunchKernelGGL((step_kernel<NT, true, EXT>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
-        else
-            hipLaunchKernelGGL((step_kernel<NT, false, EXT>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
-    } else if constexpr (!EXT) {
-        if (action_dtype == UAVX_F64)
-            hipLaunchKernelGGL((step_k_kernel<NT, true>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
-        else
-            hipLaunchKernelGGL((step_k_kernel<NT, false>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
+// Kernel variant of a handle: compile-time agent count NT (1, 2, 4, 8; 0 = runtime N), EXT (scripted bodies / curriculum),
+// W wavefronts per workgroup (runtime-N path only).  dispatch() calls l.run<NT, EXT, W>() for the handle's variant.
+template <class L>
+void dispatch(const uavx_handle *h, const L &l) {
+    if (h->ext) return l.template run<0, true, 1>();
+    switch (h->p.N) {
+        case 1: return l.template run<1, false, 1>();
+        case 2: return l.template run<2, false, 1>();
+        case 4: return l.template run<4, false, 1>();
+        case 8: return l.template run<8, false, 1>();
+        default: break;
+    }
+    switch (h->gw) {
+        case 2: return l.template run<0, false, 2>();
+        case 3: return l.template run<0, false, 3>();
+        case 4: return l.template run<0, false, 4>();
+        default: return l.template run<0, false, 1>();
     }
 }
 
-template <int NT, bool EXT>
-void launch_step_ex_nt(uavx_handle *h, dim3 grid, hipStream_t st, const StepExtra &x, const uavx_step_args *a) {
-    const dim3 blk(kBlock);
-    if (a->action_dtype == UAVX_F64)
-        hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
-    else
-        hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+struct StepLaunch {
+    uavx_handle *h; dim3 grid; hipStream_t st;
+    const void *actions; int action_dtype, evaluate, K, tape_out;
+    float *obs, *rew; uint8_t *done;
+    template <int NT, bool EXT, int W> void run() const {
+        const dim3 blk(kWave * W);
+        if (K == 1) {
+            if (action_dtype == UAVX_F64)
+                hipLaunchKernelGGL((step_kernel<NT, true, EXT, W>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+            else
+                hipLaunchKernelGGL((step_kernel<NT, false, EXT, W>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+        } else if constexpr (!EXT) {
+            if (action_dtype == UAVX_F64)
+                hipLaunchKernelGGL((step_k_kernel<NT, true, W>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
+            else
+                hipLaunchKernelGGL((step_k_kernel<NT, false, W>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
+        }
+    }
+};
+
+struct StepExLaunch {
+    uavx_handle *h; dim3 grid; hipStream_t st; StepExtra x; const uavx_step_args *a;
+    template <int NT, bool EXT, int W> void run() const {
+        const dim3 blk(kWave * W);
+        if (a->action_dtype == UAVX_F64)
+            hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+        else
+            hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT, W>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+    }
+};
+
+struct ObserveLaunch {
+    uavx_handle *h; dim3 grid; hipStream_t st; float *obs;
+    template <int NT, bool EXT, int W> void run() const {
+        hipLaunchKernelGGL((observe_kernel<NT, EXT, W>), grid, dim3(kWave * W), 0, st, h->p, obs);
+    }
+};
+
+struct ResetLaunch {
+    uavx_handle *h; dim3 grid; hipStream_t st; const uint8_t *mask; uint64_t seed;
+    template <int NT, bool EXT, int W> void run() const {
+        hipLaunchKernelGGL((reset_kernel<NT, EXT, W>), grid, dim3(kWave * W), 0, st, h->p, mask, seed);
+    }
+};
+
+// Wavefronts per workgroup for the runtime-N path: the smallest W in 1..4 whose workgroup of 64 W threads holds whole
+// envs with the fewest idle lanes, if that beats one wavefront by more than 10 % (N = 24: 48 of 64 lanes busy with
+// W = 1, 192 of 192 with W = 3; N = 5: 60 of 64 -> stays 1).
+int pick_group_waves(int N) {
+    if (N == 1 || N == 2 || N == 4 || N == 8) return 1;
+    const double u1 = (double)((kWave / N) * N) / kWave;
+    double best = u1;
+    int w = 1;
+    for (int c = 2; c <= 4; c++) {
+        const double u = (double)((kWave * c / N) * N) / (kWave * c);
+        if (u > best + 1e-9) { best = u; w = c; }
+    }
+    return best > 1.10 * u1 ? w : 1;   // a workgroup barrier replaces the wavefront-local ordering: not for a few percent
 }
 
 // float32 forms of a float64 bound b, exact for every float32 x:  (double)x >= b <=> x >= f32_at_or_above(b),
@@ -1342,8 +1456,7 @@ bool config_valid(const uavx_config *cfg) {
 }
 
 dim3 wave_grid(const uavx_handle *h) {
-    const int64_t waves = (h->p.E + h->p.epw - 1) / h->p.epw;
-    return dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
+    return dim3((unsigned)((h->p.E + h->p.epw - 1) / h->p.epw));  // one workgroup per epw envs
 }
 
 // Launches go to the handle's device; the caller's current device is restored afterwards.
@@ -1423,7 +1536,8 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const int B = cfg->num_bodies;
     p.N = N;
     p.B = B; p.nslots = N + B; p.kb = (B + N - 1) / N;
-    p.epw = std::min(kWave / N, kExtSlots / (N + B));  // an EXT wave keeps epw * (L + B) neighbour rows in LDS
+    h->gw = B > 0 ? 1 : pick_group_waves(N);
+    p.epw = std::min(kWave * h->gw / N, kExtSlots / (N + B));  // an EXT wave keeps epw * (L + B) neighbour rows in LDS
     p.magic = 65536 / N + 1;
     p.E = num_envs;
     p.env_offset = env_offset;
@@ -1601,19 +1715,7 @@ static int launch_observe(uavx_handle *h, float *obs, hipStream_t st) {
         UAVX_HIP(h, hipGetLastError());
         return UAVX_OK;
     }
-    const dim3 grid = wave_grid(h);
-    if (h->ext) {
-        hipLaunchKernelGGL((observe_kernel<0, true>), grid, dim3(kBlock), 0, st, h->p, obs);
-        UAVX_HIP(h, hipGetLastError());
-        return UAVX_OK;
-    }
-    switch (h->p.N) {
-        case 1: hipLaunchKernelGGL((observe_kernel<1, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        case 2: hipLaunchKernelGGL((observe_kernel<2, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        case 4: hipLaunchKernelGGL((observe_kernel<4, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        case 8: hipLaunchKernelGGL((observe_kernel<8, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-        default: hipLaunchKernelGGL((observe_kernel<0, false>), grid, dim3(kBlock), 0, st, h->p, obs); break;
-    }
+    dispatch(h, ObserveLaunch{h, wave_grid(h), st, obs});
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }
@@ -1636,14 +1738,7 @@ int uavx_reset(uavx_handle *h, const uint8_t *mask, uint64_t seed, float *obs, v
     h->wide = false;  // MUW:126,131,144: reset() installs float32 arrays again
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    if (h->ext) hipLaunchKernelGGL((reset_kernel<0, true>), grid, dim3(kBlock), 0, st, h->p, mask, seed);
-    else switch (h->p.N) {
-        case 1: hipLaunchKernelGGL((reset_kernel<1, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        case 2: hipLaunchKernelGGL((reset_kernel<2, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        case 4: hipLaunchKernelGGL((reset_kernel<4, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        case 8: hipLaunchKernelGGL((reset_kernel<8, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-        default: hipLaunchKernelGGL((reset_kernel<0, false>), grid, dim3(kBlock), 0, st, h->p, mask, seed); break;
-    }
+    dispatch(h, ResetLaunch{h, grid, st, mask, seed});
     UAVX_HIP(h, hipGetLastError());
     if (obs) return launch_observe(h, obs, st);
     return UAVX_OK;
@@ -1679,16 +1774,9 @@ int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, in
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    if (h->ext) {
-        if (k != 1) return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_k: k > 1 is not available with scripted bodies / a curriculum");
-        launch_step_nt<0, true>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done);
-    } else switch (h->p.N) {
-        case 1: launch_step_nt<1, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        case 2: launch_step_nt<2, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        case 4: launch_step_nt<4, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        case 8: launch_step_nt<8, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-        default: launch_step_nt<0, false>(h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done); break;
-    }
+    if (h->ext && k != 1)
+        return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_k: k > 1 is not available with scripted bodies / a curriculum");
+    dispatch(h, StepLaunch{h, grid, st, actions, action_dtype, evaluate, k, tape_out, obs, rew, done});
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }
@@ -1727,14 +1815,7 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.ended = a->ended; x.truncated = a->truncated;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    if (h->ext) launch_step_ex_nt<0, true>(h, grid, st, x, a);
-    else switch (h->p.N) {
-        case 1: launch_step_ex_nt<1, false>(h, grid, st, x, a); break;
-        case 2: launch_step_ex_nt<2, false>(h, grid, st, x, a); break;
-        case 4: launch_step_ex_nt<4, false>(h, grid, st, x, a); break;
-        case 8: launch_step_ex_nt<8, false>(h, grid, st, x, a); break;
-        default: launch_step_ex_nt<0, false>(h, grid, st, x, a); break;
-    }
+    dispatch(h, StepExLaunch{h, grid, st, x, a});
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }
