@@ -1261,6 +1261,8 @@ double sq_threshold(double lim) {
 // form returns the IEEE quotient (differences a - v of the magnitudes the kinematics produce, plus
 // the band |x| < amax*tau where the quotient is not clipped away).
 }  // namespace
+float uavx_f32_at_or_above(double b);
+float uavx_f32_at_or_below(double b);
 bool uavx_recip_division_exact(double tau) {
     const double r = 1.0 / tau;
     uint64_t s0 = 0x9E3779B97F4A7C15ull, s1 = 0xD1B54A32D192ED03ull;
@@ -1378,16 +1380,8 @@ int pick_group_waves(int N) {
 
 // float32 forms of a float64 bound b, exact for every float32 x:  (double)x >= b <=> x >= f32_at_or_above(b),
 // (double)x <= b <=> x <= f32_at_or_below(b)
-float f32_at_or_above(double b) {
-    float f = (float)b;
-    if ((double)f < b) f = std::nextafterf(f, INFINITY);
-    return f;
-}
-float f32_at_or_below(double b) {
-    float f = (float)b;
-    if ((double)f > b) f = std::nextafterf(f, -INFINITY);
-    return f;
-}
+float f32_at_or_above(double b) { return uavx_f32_at_or_above(b); }
+float f32_at_or_below(double b) { return uavx_f32_at_or_below(b); }
 
 // Everything of MultiParams that follows from the world's scalar parameters (MUW:13-58), shared by uavx_create and
 // uavx_set_config.
@@ -1476,6 +1470,17 @@ struct DeviceGuard {
     if (guard_.err != hipSuccess) return hip_fail((h), guard_.err, "hipSetDevice")
 
 }  // namespace
+
+float uavx_f32_at_or_above(double b) {   // shared with uavx_uw.hip
+    float f = (float)b;
+    if ((double)f < b) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+float uavx_f32_at_or_below(double b) {
+    float f = (float)b;
+    if ((double)f > b) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
 
 extern "C" {
 

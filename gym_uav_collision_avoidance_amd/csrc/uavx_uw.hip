@@ -2,8 +2,16 @@
 // Reference: UW = gym_uav_collision_avoidance/envs/uav_world_2d.py of dazchi/gym-uav-collision-avoidance.
 //
 // One lane per env (there is no cross-agent work): every load/store is lane-contiguous.
-// HBM layout: dyn float4[E] {x, y, prev_d, flags} r/w 16 B; vel double2[E] r/w 16 B;
-// goal float[3E] {tx, ty, init_d} read 12 B; steps u32[E] r/w; episode u32[E] (reset only).
+// HBM layout (lean: 97 B of real traffic per env-step against the 93 B algorithmic figure of SURVEY.md 8d):
+//   pos  float2[E]  {x, y}                     read+write    8 B
+//   vel  double2[E] {vx, vy}                   read+write   16 B
+//   goal {tx, ty, init_d, flags}[E]            read         16 B   (one dwordx4; the flags word is stored only when it
+//                                                                   changes: first step of an episode, arrival)
+//   prev_distance (UW:130,172) is NOT stored: it always equals ||target - location|| (reset sets it to init_distance,
+//   every step to the new distance), so it is recomputed from the loaded position; a value a caller pokes that breaks
+//   the identity lives in prev_ovr[E] behind a flag bit until the next step.
+//   steps (UW:131,170) = wave_steps[wavefront] - rec.x: a step launch bumps ONE counter per wavefront;
+//   rec uint4[E] {steps base, episode | pending << 31, running return, -}: reset / step_ex / state exchange only.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -16,23 +24,26 @@
 
 namespace uavx {
 
+struct UwGoal { float tx, ty, init_d; uint32_t flags; };
+
 struct UwParams {
     double tau, rtau, amax, vmax;  // rtau = RN(1/tau) for div_tau()
     double lox, loy, hix, hiy;
+    float lo_x, lo_y, hi_x, hi_y;  // float32 forms of the box test (exact: smallest float32 >= lox, ...)
     int recip_ok;
     float tau_f;       // float32(tau): UW:142 divides a float32 array by the python float
     float high0;       // float32(action_space.high[0]) = max_speed (test_sac.py:77)
     float inv_vmax;    // 1/max_speed[0]            UW:88
     float inv_diag;    // 1/‖(x_size,y_size)‖       UW:17,97
     int64_t E, env_offset;
-    float4 *dyn;
+    float2 *pos;
     double2 *vel;
-    float *goal;
-    uint32_t *steps, *episode;
+    UwGoal *goal;
+    float *prev_ovr;
+    uint32_t *wave_steps;
+    uint4 *rec;           // [E] {steps base, episode index | pending bit 31, running episode return (float bits), unused}
     // episode bookkeeping (uavx_uw_step_ex / uavx_uw_reset)
-    uint8_t *pending;     // [E] episode ended: re-initialise at the next step_ex call
-    float *ep_return;     // [E] running return of the current episode
-    uint4 *fin_counts;    // [E] {episodes, steps, episodes ended at the target, last-step-was-success scratch}
+    uint4 *fin_counts;    // [E] {episodes, steps, episodes ended at the target, -}
     float *fin_return;    // [E] sum of ended episodes' returns
 };
 
@@ -47,7 +58,9 @@ __device__ __forceinline__ float4 uw_obs(const UwParams &p, float speed, float t
     return make_float4(speed * p.inv_vmax, theta * kInvPi, dist_t * p.inv_diag, dth * kInvPi);
 }
 
-constexpr uint32_t kUwReached = 8u;  // internal flag bit: the last step ended at the target (d < 0.5, UW:159)
+constexpr uint32_t kUwReached = 8u;   // internal flag bit: the last step ended at the target (d < 0.5, UW:159)
+constexpr uint32_t kUwPrevOvr = 16u;  // prev_distance is prev_ovr[e], not ||target - location||
+constexpr uint32_t kUwPending = 0x80000000u;  // rec.y bit 31: episode ended, re-initialise at the next step_ex
 
 struct UwRegs {
     float x, y, prev_d, tx, ty, init_d;
@@ -71,7 +84,7 @@ __device__ __forceinline__ void uw_step_env(const UwParams &p, UwRegs &s, double
     s.vy = clip64(s.vy + clip64(qy, -p.amax, p.amax) * p.tau, -p.vmax, p.vmax);
     s.x = (float)((double)s.x + s.vx * p.tau);                                   // UW:145-146
     s.y = (float)((double)s.y + s.vy * p.tau);
-    const bool oob = !((double)s.x >= p.lox && (double)s.x <= p.hix && (double)s.y >= p.loy && (double)s.y <= p.hiy);  // UW:149,162
+    const bool oob = !(s.x >= p.lo_x && s.x <= p.hi_x && s.y >= p.lo_y && s.y <= p.hi_y);  // UW:149,162 (exact float32 form)
     const float tdx = s.tx - s.x, tdy = s.ty - s.y;
     const float d = norm32(tdx, tdy);                        // UW:150
     const float theta = atan2_fast((float)s.vy, (float)s.vx);    // UW:89
@@ -87,19 +100,25 @@ __device__ __forceinline__ void uw_step_env(const UwParams &p, UwRegs &s, double
     rew = r;
     dist = d;
     s.prev_d = d;                                            // UW:172
-    s.flags = (s.flags & ~(UAVX_FLAG_VEL_F32 | kUwReached)) | (d < 0.5f ? kUwReached : 0u);  // UW:147: velocity is float64 now
+    // UW:147: velocity is float64 now; prev_distance is the natural one again
+    s.flags = (s.flags & ~(UAVX_FLAG_VEL_F32 | kUwReached | kUwPrevOvr)) | (d < 0.5f ? kUwReached : 0u);
 }
 
 __device__ __forceinline__ void uw_load(const UwParams &p, int64_t e, UwRegs &s) {
-    const float4 d4 = p.dyn[e];
+    const float2 d2 = p.pos[e];
     const double2 v = p.vel[e];
-    s.x = d4.x; s.y = d4.y; s.prev_d = d4.z; s.flags = __float_as_uint(d4.w);
+    const UwGoal g = p.goal[e];
+    s.x = d2.x; s.y = d2.y;
     s.vx = v.x; s.vy = v.y;
-    s.tx = p.goal[3 * e]; s.ty = p.goal[3 * e + 1]; s.init_d = p.goal[3 * e + 2];
+    s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d; s.flags = g.flags;
+    s.prev_d = norm32(s.tx - s.x, s.ty - s.y);
+    if (s.flags & kUwPrevOvr) s.prev_d = p.prev_ovr[e];    // rare: only after a caller poked the state
 }
-__device__ __forceinline__ void uw_store(const UwParams &p, int64_t e, const UwRegs &s) {
-    p.dyn[e] = make_float4(s.x, s.y, s.prev_d, __uint_as_float(s.flags));
+// flags_in: the flags word as loaded (stored only if the step changed it)
+__device__ __forceinline__ void uw_store(const UwParams &p, int64_t e, const UwRegs &s, uint32_t flags_in) {
+    p.pos[e] = make_float2(s.x, s.y);
     p.vel[e] = make_double2(s.vx, s.vy);
+    if (s.flags != flags_in) p.goal[e].flags = s.flags;
 }
 template <bool ACT64>
 __device__ __forceinline__ void uw_load_action(const void *__restrict__ actions, int64_t e, double &ax, double &ay) {
@@ -120,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void uw_step_kernel(UwParams p, const void 
     if (e >= p.E) return;
     UwRegs s;
     uw_load(p, e, s);
+    const uint32_t flags_in = s.flags;
     double ax, ay;
     uw_load_action<ACT64>(actions, e, ax, ay);
     float4 obs; float rew, dist; uint32_t dn;
@@ -128,8 +148,8 @@ __global__ __launch_bounds__(kBlock) void uw_step_kernel(UwParams p, const void 
     rew_out[e] = rew;
     done_out[e] = (uint8_t)dn;
     if (info_out) info_out[e] = dist;                        // UW:114-117
-    uw_store(p, e, s);
-    p.steps[e] += 1;                                         // UW:170
+    uw_store(p, e, s, flags_in);
+    if (threadIdx.x == 0) atomicAdd(&p.wave_steps[blockIdx.x], 1u);   // UW:170 for every env of this wavefront (no-return)
 }
 
 // UW:119-131 for one env into registers; stream = the one uw_reset_kernel uses (counter: env, draw, episode).
@@ -145,17 +165,20 @@ __device__ __forceinline__ void uw_draw_episode(const UwParams &p, int64_t e, ui
     s.init_d = s.prev_d = norm32(s.tx - s.x, s.ty - s.y);                // UW:129-130
     s.flags = UAVX_FLAG_VEL_F32;
 }
+__device__ __forceinline__ void uw_store_fresh(const UwParams &p, int64_t e, const UwRegs &s) {
+    p.pos[e] = make_float2(s.x, s.y);
+    p.vel[e] = make_double2(s.vx, s.vy);
+    p.goal[e] = UwGoal{s.tx, s.ty, s.init_d, s.flags};
+}
 
 // An episode of env e ends: fold it into the statistics (test_sac.py:98,106-109).
-__device__ __forceinline__ void uw_fold(const UwParams &p, int64_t e, uint32_t steps, bool reached) {
+__device__ __forceinline__ void uw_fold(const UwParams &p, int64_t e, uint32_t steps, bool reached, float ep_return) {
     if (steps != 0) {
         uint4 c = p.fin_counts[e];
         c.x += 1; c.y += steps; c.z += reached ? 1u : 0u;
         p.fin_counts[e] = c;
-        p.fin_return[e] += p.ep_return[e];
+        p.fin_return[e] += ep_return;
     }
-    p.ep_return[e] = 0.f;
-    p.pending[e] = 0;
 }
 
 // uavx_uw_step_ex: step + polar conversion + next-step auto-reset + episode statistics.
@@ -164,51 +187,55 @@ __global__ __launch_bounds__(kBlock) void uw_step_ex_kernel(UwParams p, UwExtra 
                                                             float4 *__restrict__ obs_out, float *__restrict__ rew_out,
                                                             uint8_t *__restrict__ done_out, float *__restrict__ info_out) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= p.E) return;
-    const uint32_t pend = p.pending[e];
-    uint32_t steps = p.steps[e];
-    UwRegs s;
-    if (pend) {  // the env starts a new episode instead of stepping
-        const uint32_t episode = p.episode[e];
-        uw_fold(p, e, steps, (__float_as_uint(p.dyn[e].w) & kUwReached) != 0);
-        uw_draw_episode(p, e, episode, x.seed_lo, x.seed_hi, s);
-        p.episode[e] = episode + 1;
-        p.goal[3 * e] = s.tx; p.goal[3 * e + 1] = s.ty; p.goal[3 * e + 2] = s.init_d;
-        uw_store(p, e, s);
-        p.steps[e] = 0;                                                  // UW:131
-        const float tdx = s.tx - s.x, tdy = s.ty - s.y;
-        const float theta = atan2_fast((float)s.vy, (float)s.vx);
-        obs_out[e] = uw_obs(p, norm32((float)s.vx, (float)s.vy), theta, s.init_d, wrap_pi(atan2_fast(tdy, tdx) - theta));
-        rew_out[e] = 0.f;
-        done_out[e] = 0;
-        if (info_out) info_out[e] = s.init_d;
-        if (x.reset_mask) x.reset_mask[e] = 1;
-        return;
+    const bool live = e < p.E;
+    const uint32_t wave_count = p.wave_steps[blockIdx.x];
+    if (live) {
+        const uint4 rec = p.rec[e];
+        uint32_t steps = wave_count - rec.x;
+        UwRegs s;
+        if (rec.y & kUwPending) {  // the env starts a new episode instead of stepping
+            const uint32_t episode = rec.y & ~kUwPending;
+            uw_fold(p, e, steps, (p.goal[e].flags & kUwReached) != 0, __uint_as_float(rec.z));
+            uw_draw_episode(p, e, episode, x.seed_lo, x.seed_hi, s);
+            uw_store_fresh(p, e, s);
+            p.rec[e] = make_uint4(wave_count + 1u, episode + 1u, 0u, 0u);   // UW:131 steps = 0 after this launch
+            const float tdx = s.tx - s.x, tdy = s.ty - s.y;
+            const float theta = atan2_fast((float)s.vy, (float)s.vx);
+            obs_out[e] = uw_obs(p, norm32((float)s.vx, (float)s.vy), theta, s.init_d, wrap_pi(atan2_fast(tdy, tdx) - theta));
+            rew_out[e] = 0.f;
+            done_out[e] = 0;
+            if (info_out) info_out[e] = s.init_d;
+            if (x.reset_mask) x.reset_mask[e] = 1;
+        } else {
+            uw_load(p, e, s);
+            const uint32_t flags_in = s.flags;
+            double ax, ay;
+            uw_load_action<ACT64>(actions, e, ax, ay);
+            bool act_f32 = !ACT64;
+            if (x.action_mode == UAVX_ACTION_POLAR) {  // test_sac.py:77-80 in float32
+                const float v = fmaf((float)ax, 0.5f, 0.5f) * p.high0;
+                float sn, cs;
+                sincospi32((float)ay, sn, cs);
+                ax = (double)(v * cs); ay = (double)(v * sn);
+                act_f32 = true;
+            }
+            float4 obs; float rew, dist; uint32_t dn;
+            uw_step_env(p, s, ax, ay, act_f32, obs, rew, dn, dist);
+            obs_out[e] = obs;
+            rew_out[e] = rew;
+            done_out[e] = (uint8_t)dn;
+            if (info_out) info_out[e] = dist;
+            uw_store(p, e, s, flags_in);
+            steps += 1;                                                      // UW:170
+            const bool ended = (x.auto_reset && dn) || (x.step_cap != 0 && steps >= x.step_cap);
+            uint4 out = rec;
+            out.y = (rec.y & ~kUwPending) | (ended ? kUwPending : 0u);
+            if (x.track_returns) out.z = __float_as_uint(__uint_as_float(rec.z) + rew);   // test_sac.py:98
+            if (out.y != rec.y || out.z != rec.z) p.rec[e] = out;
+            if (x.reset_mask) x.reset_mask[e] = 0;
+        }
     }
-    uw_load(p, e, s);
-    double ax, ay;
-    uw_load_action<ACT64>(actions, e, ax, ay);
-    bool act_f32 = !ACT64;
-    if (x.action_mode == UAVX_ACTION_POLAR) {  // test_sac.py:77-80 in float32
-        const float v = fmaf((float)ax, 0.5f, 0.5f) * p.high0;
-        float sn, cs;
-        sincospi32((float)ay, sn, cs);
-        ax = (double)(v * cs); ay = (double)(v * sn);
-        act_f32 = true;
-    }
-    float4 obs; float rew, dist; uint32_t dn;
-    uw_step_env(p, s, ax, ay, act_f32, obs, rew, dn, dist);
-    obs_out[e] = obs;
-    rew_out[e] = rew;
-    done_out[e] = (uint8_t)dn;
-    if (info_out) info_out[e] = dist;
-    uw_store(p, e, s);
-    steps += 1;
-    p.steps[e] = steps;                                                  // UW:170
-    const bool ended = (x.auto_reset && dn) || (x.step_cap != 0 && steps >= x.step_cap);
-    p.pending[e] = ended ? (uint8_t)1 : (uint8_t)0;
-    if (x.track_returns) p.ep_return[e] += rew;                          // test_sac.py:98
-    if (x.reset_mask) x.reset_mask[e] = 0;
+    if (threadIdx.x == 0) p.wave_steps[blockIdx.x] = wave_count + 1u;   // single writer: this wavefront
 }
 
 __global__ __launch_bounds__(kBlock) void uw_episode_stats_kernel(UwParams p, uint32_t *counts, float *returns, int clear) {
@@ -225,12 +252,14 @@ __global__ __launch_bounds__(kBlock) void uw_episode_stats_kernel(UwParams p, ui
 __global__ __launch_bounds__(kBlock) void uw_observe_kernel(UwParams p, float4 *__restrict__ obs_out) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
-    const float4 d4 = p.dyn[e];
+    const float2 d2 = p.pos[e];
     const double2 v = p.vel[e];
-    const float tdx = p.goal[3 * e] - d4.x, tdy = p.goal[3 * e + 1] - d4.y;
+    const UwGoal g = p.goal[e];
+    const float tdx = g.tx - d2.x, tdy = g.ty - d2.y;
     const float theta = atan2_fast((float)v.y, (float)v.x);
     const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);
-    const float speed = sqrtf((float)fma(v.y, v.y, v.x * v.x));
+    // UW:88: while the velocity is still reset()'s float32 draw the norm is a float32 one
+    const float speed = (g.flags & UAVX_FLAG_VEL_F32) ? norm32((float)v.x, (float)v.y) : sqrtf((float)fma(v.y, v.y, v.x * v.x));
     obs_out[e] = uw_obs(p, speed, theta, norm32(tdx, tdy), dth);
 }
 
@@ -239,41 +268,63 @@ __global__ __launch_bounds__(kBlock) void uw_reset_kernel(UwParams p, const uint
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
     if (mask && !mask[e]) return;
-    const uint32_t episode = p.episode[e];
+    const uint4 rec = p.rec[e];
+    const uint32_t wc = p.wave_steps[blockIdx.x];
+    const uint32_t episode = rec.y & ~kUwPending;
     UwRegs s;
     uw_draw_episode(p, e, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
-    uw_fold(p, e, p.steps[e], (__float_as_uint(p.dyn[e].w) & kUwReached) != 0);
-    uw_store(p, e, s);
-    p.goal[3 * e] = s.tx; p.goal[3 * e + 1] = s.ty; p.goal[3 * e + 2] = s.init_d;
-    p.steps[e] = 0;                                                      // UW:131
-    p.episode[e] = episode + 1;
+    uw_fold(p, e, wc - rec.x, (p.goal[e].flags & kUwReached) != 0, __uint_as_float(rec.z));
+    uw_store_fresh(p, e, s);
+    p.rec[e] = make_uint4(wc, episode + 1u, 0u, 0u);                     // UW:131 steps = 0, new episode, nothing pending
 }
 
 __global__ __launch_bounds__(kBlock) void uw_get_state_kernel(UwParams p, uavx_uw_state_view v) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
-    const float4 d = p.dyn[e];
+    const float2 d = p.pos[e];
+    const UwGoal g = p.goal[e];
     if (v.loc) { v.loc[2 * e] = d.x; v.loc[2 * e + 1] = d.y; }
-    if (v.prev_d) v.prev_d[e] = d.z;
-    if (v.flags) v.flags[e] = (uint8_t)(__float_as_uint(d.w) & UAVX_FLAG_VEL_F32);
+    if (v.prev_d) v.prev_d[e] = (g.flags & kUwPrevOvr) ? p.prev_ovr[e] : norm32(g.tx - d.x, g.ty - d.y);
+    if (v.flags) v.flags[e] = (uint8_t)(g.flags & UAVX_FLAG_VEL_F32);
     if (v.vel) { const double2 w = p.vel[e]; v.vel[2 * e] = w.x; v.vel[2 * e + 1] = w.y; }
-    if (v.tgt) { v.tgt[2 * e] = p.goal[3 * e]; v.tgt[2 * e + 1] = p.goal[3 * e + 1]; }
-    if (v.init_d) v.init_d[e] = p.goal[3 * e + 2];
-    if (v.counters) { v.counters[2 * e] = p.steps[e]; v.counters[2 * e + 1] = p.episode[e]; }
+    if (v.tgt) { v.tgt[2 * e] = g.tx; v.tgt[2 * e + 1] = g.ty; }
+    if (v.init_d) v.init_d[e] = g.init_d;
+    if (v.counters) {
+        const uint4 rec = p.rec[e];
+        v.counters[2 * e] = p.wave_steps[e / kBlock] - rec.x; v.counters[2 * e + 1] = rec.y & ~kUwPending;
+    }
 }
 
+// Any subset of the fields.  prev_distance keeps the VALUE the reference would hold: what the caller does not pass
+// stays what it was, and whenever that value is not the one derived from the new (location, target) it is parked in
+// prev_ovr[] behind the PREV_OVR bit until the next step.
 __global__ __launch_bounds__(kBlock) void uw_set_state_kernel(UwParams p, uavx_uw_state_view v) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
-    float4 d = p.dyn[e];
+    float2 d = p.pos[e];
+    UwGoal g = p.goal[e];
+    const float old_prev = (g.flags & kUwPrevOvr) ? p.prev_ovr[e] : norm32(g.tx - d.x, g.ty - d.y);
     if (v.loc) { d.x = v.loc[2 * e]; d.y = v.loc[2 * e + 1]; }
-    if (v.prev_d) d.z = v.prev_d[e];
-    if (v.flags) d.w = __uint_as_float((uint32_t)v.flags[e] & UAVX_FLAG_VEL_F32);
-    p.dyn[e] = d;
+    if (v.tgt) { g.tx = v.tgt[2 * e]; g.ty = v.tgt[2 * e + 1]; }
+    if (v.init_d) g.init_d = v.init_d[e];
+    uint32_t flags = g.flags & ~kUwPrevOvr;
+    if (v.flags) flags = (flags & ~UAVX_FLAG_VEL_F32) | ((uint32_t)v.flags[e] & UAVX_FLAG_VEL_F32);
+    const float want = v.prev_d ? v.prev_d[e] : old_prev;
+    const float nat = norm32(g.tx - d.x, g.ty - d.y);
+    if (__float_as_uint(want) != __float_as_uint(nat)) {
+        flags |= kUwPrevOvr;
+        p.prev_ovr[e] = want;
+    }
+    g.flags = flags;
+    p.pos[e] = d;
+    p.goal[e] = g;
     if (v.vel) p.vel[e] = make_double2(v.vel[2 * e], v.vel[2 * e + 1]);
-    if (v.tgt) { p.goal[3 * e] = v.tgt[2 * e]; p.goal[3 * e + 1] = v.tgt[2 * e + 1]; }
-    if (v.init_d) p.goal[3 * e + 2] = v.init_d[e];
-    if (v.counters) { p.steps[e] = v.counters[2 * e]; p.episode[e] = v.counters[2 * e + 1]; }
+    if (v.counters) {
+        uint4 rec = p.rec[e];
+        rec.x = p.wave_steps[e / kBlock] - v.counters[2 * e];
+        rec.y = (rec.y & kUwPending) | (v.counters[2 * e + 1] & ~kUwPending);
+        p.rec[e] = rec;
+    }
 }
 
 }  // namespace uavx
@@ -289,6 +340,8 @@ struct uavx_uw_handle {
 };
 
 bool uavx_recip_division_exact(double tau);  // uavx_multi.hip
+float uavx_f32_at_or_above(double b);
+float uavx_f32_at_or_below(double b);
 
 namespace {
 
@@ -342,6 +395,8 @@ int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offs
     p.rtau = 1.0 / cfg->tau;
     p.recip_ok = uavx_recip_division_exact(cfg->tau) ? 1 : 0;
     p.lox = -cfg->x_size / 2.0; p.loy = -cfg->y_size / 2.0; p.hix = cfg->x_size / 2.0; p.hiy = cfg->y_size / 2.0;
+    p.lo_x = uavx_f32_at_or_above(p.lox); p.lo_y = uavx_f32_at_or_above(p.loy);
+    p.hi_x = uavx_f32_at_or_below(p.hix); p.hi_y = uavx_f32_at_or_below(p.hiy);
     p.tau_f = (float)cfg->tau;
     p.high0 = (float)cfg->max_speed;
     p.inv_vmax = (float)(1.0 / cfg->max_speed);
@@ -352,25 +407,23 @@ int uavx_uw_create(const uavx_uw_config *cfg, int64_t num_envs, int64_t env_offs
     if (guard.err != hipSuccess) { delete h; return UAVX_ERR_HIP; }
     const size_t E = (size_t)num_envs;
     size_t off = 0;
-    const size_t o_dyn = off;  off = uw_align(off + E * sizeof(float4));
+    const size_t o_pos = off;  off = uw_align(off + E * sizeof(float2));
     const size_t o_vel = off;  off = uw_align(off + E * sizeof(double2));
-    const size_t o_goal = off; off = uw_align(off + E * 3 * sizeof(float));
-    const size_t o_steps = off; off = uw_align(off + E * 4);
-    const size_t o_epi = off;   off = uw_align(off + E * 4);
-    const size_t o_pend = off;  off = uw_align(off + E);
-    const size_t o_ret = off;   off = uw_align(off + E * 4);
+    const size_t o_goal = off; off = uw_align(off + E * sizeof(UwGoal));
+    const size_t o_ovr = off;  off = uw_align(off + E * 4);
+    const size_t o_wsteps = off; off = uw_align(off + ((E + kBlock - 1) / kBlock) * 4);
+    const size_t o_rec = off;   off = uw_align(off + E * sizeof(uint4));
     const size_t o_finc = off;  off = uw_align(off + E * sizeof(uint4));
     const size_t o_finr = off;  off = uw_align(off + E * 4);
     if (hipMalloc(&h->slab, off) != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     if (hipMemset(h->slab, 0, off) != hipSuccess) { (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP; }
     char *b = static_cast<char *>(h->slab);
-    p.dyn = reinterpret_cast<float4 *>(b + o_dyn);
+    p.pos = reinterpret_cast<float2 *>(b + o_pos);
     p.vel = reinterpret_cast<double2 *>(b + o_vel);
-    p.goal = reinterpret_cast<float *>(b + o_goal);
-    p.steps = reinterpret_cast<uint32_t *>(b + o_steps);
-    p.episode = reinterpret_cast<uint32_t *>(b + o_epi);
-    p.pending = reinterpret_cast<uint8_t *>(b + o_pend);
-    p.ep_return = reinterpret_cast<float *>(b + o_ret);
+    p.goal = reinterpret_cast<UwGoal *>(b + o_goal);
+    p.prev_ovr = reinterpret_cast<float *>(b + o_ovr);
+    p.wave_steps = reinterpret_cast<uint32_t *>(b + o_wsteps);
+    p.rec = reinterpret_cast<uint4 *>(b + o_rec);
     p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
     p.fin_return = reinterpret_cast<float *>(b + o_finr);
     *out = h;
@@ -391,7 +444,8 @@ const char *uavx_uw_last_error(const uavx_uw_handle *h) { return h ? h->err.c_st
 
 int uavx_uw_observe(uavx_uw_handle *h, float *obs, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;
-    if (!obs) return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_observe: obs is NULL");
+    if (!obs || (reinterpret_cast<uintptr_t>(obs) & 15u))
+        return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_observe: obs is NULL or not 16-byte aligned");
     UW_ENTER(h);
     hipLaunchKernelGGL(uw_observe_kernel, env_grid(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->p,
                        reinterpret_cast<float4 *>(obs));
@@ -401,6 +455,8 @@ int uavx_uw_observe(uavx_uw_handle *h, float *obs, void *stream) {
 
 int uavx_uw_reset(uavx_uw_handle *h, const uint8_t *mask, uint64_t seed, float *obs, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;
+    if (obs && (reinterpret_cast<uintptr_t>(obs) & 15u))
+        return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_reset: obs not 16-byte aligned");
     UW_ENTER(h);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(uw_reset_kernel, env_grid(h), dim3(kBlock), 0, st, h->p, mask, seed);
@@ -418,6 +474,9 @@ int uavx_uw_step(uavx_uw_handle *h, const void *actions, int action_dtype, float
     if (!actions || !obs || !rew || !done) return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step: NULL buffer");
     if (action_dtype != UAVX_F32 && action_dtype != UAVX_F64)
         return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step: action_dtype must be UAVX_F32 or UAVX_F64");
+    if ((reinterpret_cast<uintptr_t>(obs) & 15u) || (reinterpret_cast<uintptr_t>(actions) & (action_dtype == UAVX_F64 ? 15u : 7u)) ||
+        (reinterpret_cast<uintptr_t>(rew) & 3u) || (reinterpret_cast<uintptr_t>(info_distance) & 3u))
+        return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step: obs must be 16-byte aligned, actions 8 (float32) / 16 (float64), rew and info 4");
     UW_ENTER(h);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (action_dtype == UAVX_F64)
@@ -437,6 +496,9 @@ int uavx_uw_step_ex(uavx_uw_handle *h, const uavx_uw_step_args *a, void *stream)
         return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step_ex: action_dtype must be UAVX_F32 or UAVX_F64");
     if (a->action_mode != UAVX_ACTION_CARTESIAN && a->action_mode != UAVX_ACTION_POLAR)
         return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step_ex: unknown action_mode");
+    if ((reinterpret_cast<uintptr_t>(a->obs) & 15u) || (reinterpret_cast<uintptr_t>(a->actions) & (a->action_dtype == UAVX_F64 ? 15u : 7u)) ||
+        (reinterpret_cast<uintptr_t>(a->rew) & 3u) || (reinterpret_cast<uintptr_t>(a->info_distance) & 3u))
+        return uw_fail(h, UAVX_ERR_INVALID_ARG, "uavx_uw_step_ex: obs must be 16-byte aligned, actions 8 (float32) / 16 (float64), rew and info 4");
     UW_ENTER(h);
     UwExtra x;
     x.action_mode = a->action_mode; x.auto_reset = a->auto_reset; x.track_returns = a->track_returns;

@@ -6,6 +6,8 @@ The reference has no scripted obstacle and no per-env worlds (SURVEY.md ยง0.3, ย
 restatement of the same definition (oracle/uavx_oracle.c: uavo_*_x) -- bit-exact on masks, learner state, body records,
 levels and counters, 1e-5 on observations / rewards -- with the learners' own step still the reference-pinned one (an
 extension handle with no bodies and one level equal to the config must reproduce the plain kernels bit for bit)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -266,6 +268,31 @@ def test_extension_argument_checks(amd):
             env.step_ex(a, out=bad)
     with pytest.raises(ValueError):
         amd.BatchedMultiUAVWorld2D(8, num_agents=40, num_bodies=30)         # more than 64 slots
+    env.close()
+
+
+def test_uw_entry_points_reject_misaligned_buffers(amd):
+    """uavx_uw_* cast obs to float4 and load float2 / double2 actions: a sliced (misaligned) view must be refused with
+    UAVX_ERR_INVALID_ARG instead of faulting on the GPU."""
+    import torch
+    from gym_uav_collision_avoidance_amd import _lib
+    env = amd.BatchedUAVWorld2D(128)
+    env.reset()
+    L, h, st = env._L, env._h, env._stream()
+    obs = torch.zeros(128 * 4 + 4, device=env.device)
+    act = torch.zeros(128 * 2 + 2, device=env.device)
+    rew = torch.zeros(128, device=env.device)
+    done = torch.zeros(128, dtype=torch.uint8, device=env.device)
+    ok = L.uavx_uw_step(h, act.data_ptr(), _lib.F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), None, st)
+    assert ok == 0
+    assert L.uavx_uw_step(h, act.data_ptr(), _lib.F32, obs.data_ptr() + 4, rew.data_ptr(), done.data_ptr(), None, st) == -1
+    assert L.uavx_uw_step(h, act.data_ptr() + 4, _lib.F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), None, st) == -1
+    assert L.uavx_uw_step(h, act.data_ptr() + 8, _lib.F64, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), None, st) == -1
+    assert L.uavx_uw_observe(h, obs.data_ptr() + 8, st) == -1
+    assert L.uavx_uw_reset(h, None, 0, obs.data_ptr() + 4, st) == -1
+    args = _lib.UWStepArgs(act.data_ptr(), _lib.F32, 0, 0, 0, 0, 0, 0, obs.data_ptr() + 4, rew.data_ptr(), done.data_ptr(), None, None)
+    assert L.uavx_uw_step_ex(h, ctypes.byref(args), st) == -1
+    assert b"aligned" in L.uavx_uw_last_error(h)
     env.close()
 
 
