@@ -50,6 +50,60 @@ def evaluate_policy(policy_fn, num_agents, episodes=100, max_steps=2000, evaluat
     return out
 
 
+@torch.no_grad()
+def rollout_trajectories(policy_fn, num_agents, episodes=1, max_steps=2000, circular=True, layout=None, polar=True,
+                         evaluate=False, seed=0, device=None, **env_kwargs):
+    """The plotting scenario of test_sac_multi_plot_trajectory.py:43-76 for `episodes` worlds side by side: reset, place
+    the UAVs (circular=True: MUW:157-163's circle; layout=(loc [N,2], tgt [N,2]) float64: the script's own pokes,
+    :46-47, e.g. with its OFFSET), then step until all(dones) (:75) or max_steps, recording every agent's location
+    BEFORE each step (:66) and feeding agents whose `done` flag is set a zero command (:57-59).
+
+    policy_fn(obs [E,N,10]) -> actions [E,N,2] (policy outputs in [-1,1]^2 with polar=True, :61-63; velocity commands
+    otherwise).  Returns dict(positions [T,E,N,2] (float64 when the episode runs in float64-position mode, as the
+    reference's does after such pokes), valid [T,E,N] bool (False once the agent is done, or after its world's episode
+    is over: the script stops appending), depots [E,N,2], goals [E,N,2], length [E] steps until all(dones) / the cap)."""
+    env = BatchedMultiUAVWorld2D(episodes, num_agents=num_agents, device=device, seed=seed, **env_kwargs)
+    E, N, dev = episodes, num_agents, env.device
+    obs = env.reset()
+    if layout is not None:
+        loc = torch.as_tensor(layout[0], dtype=torch.float64).reshape(N, 2)
+        tgt = torch.as_tensor(layout[1], dtype=torch.float64).reshape(N, 2)
+        # what the script's assignments leave behind: init / prev distances keep reset()'s values (it does not touch them)
+        env.set_state_f64(loc=loc.expand(E, N, 2), tgt=tgt.expand(E, N, 2))
+        obs = env.observe()
+    elif circular:
+        obs = env.reset_circular()
+    wide = env.position_mode == "float64"
+
+    def locations():
+        return env.get_state_f64()["loc"] if wide else env.get_state()["loc"]
+
+    depots = locations().clone()
+    goals = (env.get_state_f64()["tgt"] if wide else env.get_state()["tgt"]).clone()
+    ended = torch.zeros(E, dtype=torch.bool, device=dev)
+    length = torch.zeros(E, dtype=torch.int64, device=dev)
+    pos, valid = [], []
+    for t in range(max_steps):
+        done_flag = (env.get_state()["flags"] & 1) != 0                    # env.agent_list[i].done, :57
+        act = policy_fn(obs).to(torch.float32).clone()
+        if polar:
+            act[..., 0] = torch.where(done_flag, torch.full_like(act[..., 0], -1.0), act[..., 0])   # v = 0 -> command (0, 0)
+        else:
+            act = torch.where(done_flag[..., None], torch.zeros_like(act), act)
+        pos.append(locations().clone())                                     # :66 (before the step)
+        valid.append(~done_flag & ~ended[:, None])
+        obs, rew, done, _ = env.step_ex(act, evaluate=evaluate, polar=polar, track_returns=False)
+        newly = ~ended & done.all(dim=1)                                    # :75
+        length = torch.where(newly, torch.full_like(length, t + 1), length)
+        ended |= newly
+        if t % 16 == 15 and bool(ended.all()):
+            break
+    length = torch.where(ended, length, torch.full_like(length, len(pos)))
+    out = dict(positions=torch.stack(pos), valid=torch.stack(valid), depots=depots, goals=goals, length=length)
+    env.close()
+    return out
+
+
 def sweep_num_agents(policy_fn, agent_counts=range(1, 25), episodes=100, max_steps=2000, **kw):
     """SR / CR versus the number of UAVs like test_sac_multi_score.py:31-80."""
     return [evaluate_policy(policy_fn, n, episodes=episodes, max_steps=max_steps, **kw) for n in agent_counts]

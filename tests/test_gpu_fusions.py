@@ -296,6 +296,43 @@ def test_circular_scenario_and_agent_sweep(amd):
     assert all(0.0 <= r["success_rate"] <= 1.0 and r["collision_rate"] >= 0.0 for r in res)
 
 
+def test_trajectory_rollout_matches_the_reference_circular_episode(amd):
+    """evaluate.rollout_trajectories (the plotting scenario, test_sac_multi_plot_trajectory.py:43-76) replaying the actions
+    of the reference's recorded reset(circular=True) episodes: every recorded location is the reference's float64 location
+    bit for bit, agents stop being recorded exactly when their done flag is set, the episode ends at all(dones)."""
+    import os
+    import torch
+    from gym_uav_collision_avoidance_amd.evaluate import rollout_trajectories
+    for n in (4, 6):
+        fx = np.load(os.path.join(os.path.dirname(__file__), "golden", f"crafted_circular_n{n}.npz"))
+        acts = torch.from_numpy(fx["actions"]).to("cuda")          # [T, N, 2] float64 velocity commands
+        E, T = 3, acts.shape[0]
+        step = {"t": 0}
+
+        def replay(obs):
+            a = acts[min(step["t"], T - 1)].to(torch.float32)       # the fixture's commands are float32-representable? no:
+            step["t"] += 1                                          # they are float64 -> checked below
+            return a[None].expand(E, n, 2)
+
+        # the recorded commands must survive the float32 policy-output path of the harness unchanged
+        if not np.array_equal(fx["actions"].astype(np.float32).astype(np.float64), fx["actions"]):
+            pytest.skip("fixture actions are not float32-representable")
+        out = rollout_trajectories(replay, n, episodes=E, max_steps=T, circular=True, polar=False)
+        pos, valid, length = _np(out["positions"]), _np(out["valid"]), _np(out["length"])
+        want = np.concatenate([fx["init_loc"][None], fx["loc"][:-1]], axis=0)          # location BEFORE step t
+        done_before = np.concatenate([np.zeros((1, n), bool), (fx["flags"][:-1] & 1) != 0], axis=0)
+        all_done = np.where(fx["done"].all(axis=1))[0]
+        L = int(all_done[0]) + 1 if len(all_done) else T
+        assert (length == L).all(), (length, L)
+        assert out["positions"].dtype == torch.float64
+        for e in range(E):
+            np.testing.assert_array_equal(pos[:L, e], want[:L])
+            np.testing.assert_array_equal(valid[:L, e], ~done_before[:L])
+        assert not valid[L:].any()
+        np.testing.assert_array_equal(_np(out["depots"])[0], fx["init_loc"])
+        np.testing.assert_array_equal(_np(out["goals"])[0], fx["init_tgt"])
+
+
 def test_reference_checkpoint_layout_and_batched_policy(amd, tmp_path):
     """A file with the reference's SAC.save_checkpoint layout (sac.py:108-112) loads into the batched actor."""
     import torch

@@ -214,3 +214,33 @@ def test_lane_to_env_multiply_shift_is_exact():
     for n in range(1, 65):
         magic = 65536 // n + 1
         assert all(((lane * magic) >> 16) == lane // n for lane in range(64)), n
+
+
+def test_checkpoint_written_in_the_reference_layout(tmp_path):
+    """policy.save_reference_checkpoint writes the five keys of SAC.save_checkpoint (pytorch_sac_temp/sac.py:108-112) with
+    state dicts that reference-shaped modules and Adam optimisers load; the policy part round-trips through the loader."""
+    from gym_uav_collision_avoidance_amd.policy import (CHECKPOINT_KEYS, GaussianPolicy, TwinQ, load_reference_checkpoint,
+                                                        save_reference_checkpoint)
+    torch.manual_seed(0)
+    pol = GaussianPolicy()
+    popt = torch.optim.Adam(pol.parameters(), lr=3e-4)
+    mean, log_std = pol(torch.randn(5, 10))
+    (mean.sum() + log_std.sum()).backward()
+    popt.step()                                            # an optimiser WITH state (exp_avg, exp_avg_sq, step)
+    f = save_reference_checkpoint(str(tmp_path / "ckpt" / "weights.chpt"), pol, policy_optimizer=popt)
+    ck = torch.load(f, weights_only=True)                  # tensors and plain containers only
+    assert tuple(ck) == CHECKPOINT_KEYS
+    assert set(ck["critic_state_dict"]) == {f"linear{i}.{w}" for i in range(1, 7) for w in ("weight", "bias")}
+    assert ck["critic_state_dict"]["linear1.weight"].shape == (256, 12) and ck["critic_state_dict"]["linear6.weight"].shape == (1, 256)
+    for k in ck["critic_state_dict"]:
+        assert torch.equal(ck["critic_state_dict"][k], ck["critic_target_state_dict"][k])     # hard_update, sac.py:26
+    # what SAC.load_checkpoint does (sac.py:126-130) with modules / optimisers of the reference's shapes
+    pol2, q, qt = GaussianPolicy(), TwinQ(), TwinQ()
+    pol2.load_state_dict(ck["policy_state_dict"]); q.load_state_dict(ck["critic_state_dict"]); qt.load_state_dict(ck["critic_target_state_dict"])
+    torch.optim.Adam(q.parameters(), lr=3e-4).load_state_dict(ck["critic_optimizer_state_dict"])
+    o2 = torch.optim.Adam(pol2.parameters(), lr=3e-4)
+    o2.load_state_dict(ck["policy_optimizer_state_dict"])
+    assert len(o2.state_dict()["state"]) == 8              # 4 layers x (weight, bias) carry their Adam moments
+    back = load_reference_checkpoint(f, device="cpu")
+    for a, b in zip(pol.state_dict().values(), back.state_dict().values()):
+        assert torch.equal(a, b)
