@@ -85,7 +85,8 @@ def rollout_trajectories(policy_fn, num_agents, episodes=1, max_steps=2000, circ
     pos, valid = [], []
     for t in range(max_steps):
         done_flag = (env.get_state()["flags"] & 1) != 0                    # env.agent_list[i].done, :57
-        act = policy_fn(obs).to(torch.float32).clone()
+        act = policy_fn(obs)
+        act = (act if act.dtype in (torch.float32, torch.float64) else act.to(torch.float32)).clone()
         if polar:
             act[..., 0] = torch.where(done_flag, torch.full_like(act[..., 0], -1.0), act[..., 0])   # v = 0 -> command (0, 0)
         else:
