@@ -183,28 +183,36 @@ class Stepper:
                 self.step(self.ring[i % self.R])
 
 
-def timed_regions(stepper, K, repeats, device, dist=None):
-    """`repeats` regions of exactly K step launches; returns per-region (wall s, device ms) lists (this rank)."""
-    walls, devs = [], []
+def timed_regions(stepper, K, repeats, device, dist=None, events=False):
+    """`repeats` regions of exactly K step launches, each bracketed by barrier + synchronize on both sides.  events=False:
+    wall-clock regions (nothing but the K launches between the two clock reads); events=True: the same regions bracketed by
+    HIP events on the launch stream instead (device time of the K steps; the two event records would otherwise sit inside
+    the wall-clock region).  Returns the per-region times of this rank (s or ms)."""
+    out = []
     for _ in range(repeats):
         torch.cuda.synchronize(device)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        stepper.run(K)
-        ev1.record()
-        while not ev1.query():      # spin instead of a blocking wait: the wake-up latency of a sleeping host thread
-            pass                    # (tens of us) would otherwise be charged to a K-step region of ~100 us
-        t1 = time.perf_counter()
-        torch.cuda.synchronize(device)
+        if events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            stepper.run(K)
+            ev1.record()
+            torch.cuda.synchronize(device)
+            out.append(ev0.elapsed_time(ev1))  # HIP events on the stream the kernels were launched on
+        else:
+            done = torch.cuda.Event()
+            t0 = time.perf_counter()
+            stepper.run(K)
+            done.record()
+            while not done.query():     # spin instead of a blocking wait: the wake-up latency of a sleeping host thread
+                pass                    # (tens of us) would otherwise be charged to a K-step region of ~100 us
+            out.append(time.perf_counter() - t0)
+            torch.cuda.synchronize(device)
         if dist is not None:
             dist.barrier()
-        walls.append(t1 - t0)
-        devs.append(ev0.elapsed_time(ev1))  # HIP events on the stream the kernels were launched on
-    return walls, devs
+    return out
 
 
 def single_step_latency(step, ring, device, trials=200):
@@ -234,7 +242,7 @@ def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60)
     st = Stepper(env.step, ring, device, "graph")
     st.prepare(steps)
     st.run(warmup)
-    walls, devs = timed_regions(st, steps, 3, device)
+    devs = timed_regions(st, steps, 3, device, events=True)
     kernel_s = statistics.median(devs) * 1e-3 / steps
     b = algorithmic_bytes_per_env_step(N, bodies) * E
     ws = working_set_bytes(E, N + bodies, L, ring.shape[0])
@@ -337,7 +345,8 @@ def main():
     if distributed:
         gather_episode_metrics(read_counters(), dst=0)  # warm the communicator
 
-    walls, devs = timed_regions(stepper, K, max(1, args.repeats), device, dist)
+    walls = timed_regions(stepper, K, max(1, args.repeats), device, dist)
+    devs = timed_regions(stepper, K, max(1, args.repeats), device, dist, events=True)   # device time, in regions of their own
 
     # episode-metrics path (test_sac_multi.py:164-165): counters read + ONE gather to rank 0, timed on its own
     torch.cuda.synchronize(device)
@@ -406,7 +415,7 @@ def main():
                            "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",
             "ms_per_step_incl_amortised_gather": elapsed * 1e3 / K + gather_s * 1e3 / 1500.0,
             "episode_metrics": summ,
-            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * len(walls),
+            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + len(devs)),
         }
         if world == 1:
             line["latency_us"] = {"single_step_launch_to_done": single_step_latency(step, ring, device),
