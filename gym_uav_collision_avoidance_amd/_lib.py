@@ -19,7 +19,7 @@ F32, F64 = 0, 1
 SYMBOLS = (
     "uavx_version", "uavx_selftest", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
     "uavx_num_agents", "uavx_set_config", "uavx_set_body_rule", "uavx_num_bodies", "uavx_get_bodies", "uavx_set_bodies",
-    "uavx_set_curriculum", "uavx_set_env_levels", "uavx_get_env_levels", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
+    "uavx_set_curriculum", "uavx_set_env_levels", "uavx_get_env_levels", "uavx_set_prefetch", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
     "uavx_set_state", "uavx_set_position_mode", "uavx_get_position_mode", "uavx_set_state_f64", "uavx_get_state_f64",
     "uavx_get_metrics", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
     "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
@@ -166,6 +166,7 @@ def load():
     L.uavx_set_curriculum.argtypes = [vp, ctypes.POINTER(Level), i32, i32, i32, vp]
     L.uavx_set_env_levels.argtypes = [vp, vp, vp]
     L.uavx_get_env_levels.argtypes = [vp, vp, vp]
+    L.uavx_set_prefetch.argtypes = [vp, i32]
     L.uavx_reset.argtypes = [vp, vp, u64, vp, vp]
     L.uavx_step.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     L.uavx_step_k.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp]

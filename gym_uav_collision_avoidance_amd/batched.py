@@ -213,6 +213,11 @@ class BatchedMultiUAVWorld2D(_Base):
         _lib.check(self._L.uavx_get_env_levels(self._h, t.data_ptr(), self._stream()), self._h)
         return t
 
+    def set_prefetch(self, every=16):
+        """Pre-drawn reset layouts (uavx_set_prefetch): the layouts of the episodes that start next are drawn by a side
+        kernel on every `every`-th step_ex call; 0 / False = off (every auto-reset draws inside the step launch)."""
+        _lib.check(self._L.uavx_set_prefetch(self._h, int(every)), self._h)
+
     def get_bodies(self):
         """[E, B, 4] float32 {x, y, waypoint x, waypoint y}; a body switched off by its env's level sits at +inf."""
         t = torch.empty((self.num_envs, self.num_bodies, 4), dtype=torch.float32, device=self.device)

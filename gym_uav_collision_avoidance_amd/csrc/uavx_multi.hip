@@ -106,7 +106,18 @@ struct MultiParams {
     float4 *body;                 // [E*B] {x, y, wx, wy}
     uint8_t *lvl_cur, *lvl_next;  // [E] level in force / level assigned for the next reset
     const LevelParams *levels;    // [UAVX_MAX_LEVELS]; entry 0 mirrors the handle's config while no curriculum is installed
+    // ---- pre-drawn layouts (uavx_step_ex auto-reset; see prefetch_kernel) ----
+    // The layout of an env's NEXT episode is a pure function of (seed, global env, episode index, level rule), so it is
+    // drawn ahead of time by a kernel that runs BESIDE the step launch and parked here; the step launch that re-initialises
+    // the env then copies 16 B per slot instead of running the serial accept / reject chain on one wavefront while the
+    // rest of the chip waits for it.  stage_tag says exactly what a parked layout was drawn for; anything else is a miss
+    // and falls back to drawing in the step launch.
+    float4 *stage_agent;          // [E*L] {sx, sy, tx, ty}
+    float4 *stage_body;           // [E*B] {x, y, wx, wy}
+    uint4 *stage_tag;             // [E] {episode index, seed lo, seed hi, level | world version << 8 | valid << 31}
+    uint32_t world_version;       // bumped by every call that changes what a layout depends on (config, curriculum, body rule)
 };
+constexpr uint32_t kStageValid = 0x80000000u;
 constexpr uint32_t kRecEnded = 0x80000000u;  // env_rec.y bit 31: episode ended, re-initialise at the next step_ex
 constexpr uint32_t kFlagInactive = UAVX_FLAG_INACTIVE;
 constexpr int kLevelShift = 8;       // Goal::flags bits 8..11: the env's curriculum level (same value in every agent of the env)
@@ -120,6 +131,7 @@ struct StepExtra {
     uint32_t seed_lo, seed_hi;
     uint8_t *reset_mask;
     uint8_t *ended, *truncated;
+    int use_stage;   // consult the pre-drawn layouts (prefetch_kernel runs beside this launch)
 };
 
 struct LaneMap {
@@ -683,9 +695,12 @@ __device__ __forceinline__ bool too_close(float sq_two_r, float ax, float ay, fl
 // the level's bodies then draw their start points in slot order by the same chain, trip by trip (body b belongs to
 // lane b % L, trip b / L), against the learners' accepted starts and the lower-indexed bodies, and take waypoint 0.
 // Body records are stored by this function; the rows of the bodies that take part stay in LDS as {x, y, wx, wy}.
+// body_out / lvl_out: where the body records and the env's level go -- the live arrays (p.body, p.lvl_cur), or the staging
+// area of a pre-drawn layout (p.stage_body, nullptr: the level then only travels in s.flags).
 template <int NT, bool EXT, class LDS>
 __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, LDS &lds, bool go,
-                                                uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s) {
+                                                uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s,
+                                                float4 *body_out, uint8_t *lvl_out) {
     const int N = NT ? NT : p.N;
     float4 *row = &lds.pos[m.rbase];
     const uint64_t ge = (uint64_t)p.env_offset + m.e;
@@ -801,7 +816,7 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                     rec = make_float4(qx, qy, w0.sx, w0.sy);
                     row[slot] = rec;
                 }
-                p.body[m.e * (uint32_t)p.B + (uint32_t)b] = rec;
+                body_out[m.e * (uint32_t)p.B + (uint32_t)b] = rec;
             }
         }
     }
@@ -817,9 +832,22 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                 s.init_d = s.prev_d = INFINITY;
                 s.flags |= kFlagInactive;
             }
-            if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)lvl;
+            if (m.i == 0 && lvl_out) lvl_out[m.e] = (uint8_t)lvl;
         }
     }
+}
+
+// What a parked layout must have been drawn for to serve env e's next reset: {episode index, seed, level rule | world
+// version | valid}.  With an installed curriculum and the random window off the level is the one assigned to the env.
+template <bool EXT>
+__device__ __forceinline__ uint4 stage_want(const MultiParams &p, uint32_t e, uint32_t episode, uint32_t k0, uint32_t k1) {
+    uint32_t lvl = 0xFFu;   // "drawn by the layout itself" (random window) or no curriculum
+    if (EXT && p.n_levels > 0 && p.level_lo < 0) lvl = min((uint32_t)p.lvl_next[e], (uint32_t)(p.n_levels - 1));
+    return make_uint4(episode, k0, k1, kStageValid | ((p.world_version & 0x7FFFFFu) << 8) | lvl);
+}
+__device__ __forceinline__ bool stage_hit(uint4 have, uint4 want) {   // the level byte of `have` is the level it drew
+    const bool lvl_ok = (want.w & 0xFFu) == 0xFFu || (want.w & 0xFFu) == (have.w & 0xFFu);
+    return have.x == want.x && have.y == want.y && have.z == want.z && (have.w >> 8) == (want.w >> 8) && lvl_ok;
 }
 
 // An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation
@@ -910,7 +938,39 @@ __global__ __launch_bounds__(kWave * W) void step_ex_kernel(MultiParams p, StepE
         // step arithmetic.
         __builtin_amdgcn_s_setprio(3);
         if (do_reset && m.i == 0) fold = fold_load(p, m.e);
-        reset_envs_wave<NT, EXT>(p, m, lds, do_reset, episode, x.seed_lo, x.seed_hi, fresh);
+        // the layout was normally drawn ahead of time by prefetch_kernel (16-byte copies); only a miss -- first use, a
+        // changed seed / world, an episode shorter than one call -- draws here
+        bool hit = false;
+        uint4 tag = make_uint4(0, 0, 0, 0);
+        if (do_reset && x.use_stage) {
+            tag = p.stage_tag[m.e];
+            hit = stage_hit(tag, stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
+        }
+        if (group_any<W>(do_reset && !hit))
+            reset_envs_wave<NT, EXT>(p, m, lds, do_reset && !hit, episode, x.seed_lo, x.seed_hi, fresh, p.body, p.lvl_cur);
+        if (hit) {
+            const float4 st = p.stage_agent[m.a];
+            fresh.x = st.x; fresh.y = st.y; fresh.tx = st.z; fresh.ty = st.w;
+            fresh.vx = 0.0; fresh.vy = 0.0; fresh.flags = 0;                 // MUW:120-123
+            bool parked = false;
+            if (EXT) {
+                const uint32_t lvl = tag.w & 0xFFu;
+                const LevelParams *lv = &p.levels[lvl];
+                parked = m.i >= lv->n_active;
+                fresh.flags = (lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
+                if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)lvl;
+#pragma unroll 1
+                for (int k = 0; k < p.kb; k++) {   // the bodies' records: staged -> live, and into the env's LDS rows
+                    const int b = k * N + m.i;
+                    if (b < p.B) {
+                        const float4 r = p.stage_body[m.e * (uint32_t)p.B + (uint32_t)b];
+                        p.body[m.e * (uint32_t)p.B + (uint32_t)b] = r;
+                        lds.pos[m.rbase + N + b] = r;
+                    }
+                }
+            }
+            fresh.init_d = fresh.prev_d = parked ? INFINITY : norm32(fresh.tx - fresh.x, fresh.ty - fresh.y);  // MUW:154-155
+        }
         if (do_reset) {
             p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d, fresh.flags};
             steps_v = 0;                                           // MUW:166
@@ -1086,7 +1146,7 @@ __global__ __launch_bounds__(kWave * W) void reset_kernel(MultiParams p, const u
         fold = fold_load(p, m.e);
         wc = p.wave_steps[m.wave];
     }
-    reset_envs_wave<NT, EXT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s);
+    reset_envs_wave<NT, EXT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s, p.body, p.lvl_cur);
     if (go) {
         p.pos[m.a] = make_float2(s.x, s.y);
         p.vel[m.a] = make_double2(0.0, 0.0);
@@ -1094,6 +1154,38 @@ __global__ __launch_bounds__(kWave * W) void reset_kernel(MultiParams p, const u
         if (m.i == 0) {
             fold_store(p, m.e, wc - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold);
             p.env_rec[m.e] = make_uint4(wc, episode + 1u, 0u, 0u);  // MUW:166 steps = 0, new episode, no running return
+        }
+    }
+}
+
+// Draws the layout of every env's NEXT episode that is not parked yet (or parked for something else: other seed, world
+// version, level) into the staging arrays.  Same mapping and the same reset_envs_wave as reset_kernel, outputs redirected.
+// Launched on the handle's side stream next to every n-th uavx_step_ex launch and joined after it: the serial accept /
+// reject chains of the envs that need a layout run in ONE launch per n steps (and beside the step where the runtime
+// overlaps the two) instead of at the tail of every step launch.  Safe against the concurrent step
+// launch: that launch only READS the staging arrays of an env it re-initialises, and it publishes the env's new episode
+// index (env_rec.y) after those reads have returned -- so this kernel either sees the old index (and finds the parked
+// layout still right: nothing to do) or the new one (and may overwrite a layout that has been consumed).
+template <int NT, bool EXT, int W>
+__global__ __launch_bounds__(kWave * W) void prefetch_kernel(MultiParams p, uint32_t k0, uint32_t k1) {
+    using LDS = LdsT<EXT, W>;
+    __shared__ LDS lds;
+    const LaneMap m = lane_map<NT, EXT, W>(p);
+    uint32_t episode = 0;
+    bool need = false;
+    if (m.active) {
+        episode = p.env_rec[m.e].y & ~kRecEnded;   // the index the env's next reset draws with
+        need = !stage_hit(p.stage_tag[m.e], stage_want<EXT>(p, m.e, episode, k0, k1));
+    }
+    if (!group_any<W>(need)) return;
+    AgentRegs s = {};
+    reset_envs_wave<NT, EXT>(p, m, lds, need, episode, k0, k1, s, p.stage_body, nullptr);
+    if (need) {
+        p.stage_agent[m.a] = make_float4(s.x, s.y, s.tx, s.ty);
+        if (m.i == 0) {
+            uint4 tag = stage_want<EXT>(p, m.e, episode, k0, k1);
+            tag.w = (tag.w & ~0xFFu) | (EXT ? ((s.flags & kLevelMask) >> kLevelShift) : 0u);   // the level it drew
+            p.stage_tag[m.e] = tag;
         }
     }
 }
@@ -1226,6 +1318,11 @@ struct uavx_handle {
     void *wide_slab = nullptr;
     // configs[4] extension: scripted bodies and / or an installed curriculum select the EXT kernel variants
     int gw = 1;  // wavefronts per workgroup of the step / reset / observe launches (pick_group_waves)
+    // pre-drawn layouts: prefetch_kernel runs on `side` next to every prefetch_every-th auto-resetting uavx_step_ex launch
+    int prefetch_every = 16;   // 0: off
+    uint64_t ex_calls = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ext = false;
     uavx_body_rule rule = {5.0, 128, 0, 0};
     LevelTable levels = {};
@@ -1353,6 +1450,13 @@ struct ObserveLaunch {
     uavx_handle *h; dim3 grid; hipStream_t st; float *obs;
     template <int NT, bool EXT, int W> void run() const {
         hipLaunchKernelGGL((observe_kernel<NT, EXT, W>), grid, dim3(kWave * W), 0, st, h->p, obs);
+    }
+};
+
+struct PrefetchLaunch {
+    uavx_handle *h; dim3 grid; hipStream_t st; uint32_t k0, k1;
+    template <int NT, bool EXT, int W> void run() const {
+        hipLaunchKernelGGL((prefetch_kernel<NT, EXT, W>), grid, dim3(kWave * W), 0, st, h->p, k0, k1);
     }
 };
 
@@ -1547,6 +1651,9 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.E = num_envs;
     p.env_offset = env_offset;
     h->ext = B > 0;
+    // pre-drawn layouts pay where drawing inside the step launch is expensive: from 8 slots per env on (A/B in
+    // profiles/r02_ab_notes.md: 8 + 16 bodies 37.1 -> 24.9 us per fused step; 4 agents 7.8 -> 8.6, so off there)
+    h->prefetch_every = (N + B >= 8) ? 16 : 0;
     apply_body_rule(h);
     h->levels.l[0] = make_level(*cfg, nullptr, N, B);
 
@@ -1569,6 +1676,9 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_lcur = off;  off = align_up(off + E, 256);
     const size_t o_lnext = off; off = align_up(off + E, 256);
     const size_t o_levels = off; off = align_up(off + sizeof(LevelTable), 256);
+    const size_t o_sagent = off; off = align_up(off + A * sizeof(float4), 256);
+    const size_t o_sbody = off;  off = align_up(off + E * (size_t)B * sizeof(float4), 256);
+    const size_t o_stag = off;   off = align_up(off + E * sizeof(uint4), 256);
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     e = hipMemset(h->slab, 0, off);
@@ -1590,6 +1700,15 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     h->levels_dev = reinterpret_cast<LevelParams *>(b + o_levels);
     p.levels = h->levels_dev;
     p.n_levels = 0; p.level_lo = -1; p.level_hi = -1;
+    p.stage_agent = reinterpret_cast<float4 *>(b + o_sagent);
+    p.stage_body = reinterpret_cast<float4 *>(b + o_sbody);
+    p.stage_tag = reinterpret_cast<uint4 *>(b + o_stag);   // zero-filled: no layout is valid yet
+    p.world_version = 1;
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP;
+    }
     hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);  // level 0 = the config
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(0);
@@ -1602,6 +1721,9 @@ int uavx_destroy(uavx_handle *h) {
     if (!h) return UAVX_ERR_INVALID_ARG;
     if (h->slab) {
         DeviceGuard guard(h->device);
+        if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
         (void)hipFree(h->slab);
         if (h->wide_slab) (void)hipFree(h->wide_slab);
     }
@@ -1620,6 +1742,7 @@ int uavx_set_config(uavx_handle *h, const uavx_config *cfg) {
     derive_world_params(*cfg, h->p);  // kernel arguments are taken by value at launch: later launches see the new world
     h->wl = derive_wide_limits(*cfg);
     apply_body_rule(h);
+    h->p.world_version++;             // pre-drawn layouts of the old world are stale
     if (h->ext) {  // EXT kernels read the world from level 0 of the device table
         UAVX_ENTER(h);
         h->levels.l[0] = make_level(*cfg, nullptr, h->p.N, h->p.B);
@@ -1631,12 +1754,20 @@ int uavx_set_config(uavx_handle *h, const uavx_config *cfg) {
 
 int uavx_num_bodies(const uavx_handle *h) { return h ? h->p.B : -1; }
 
+int uavx_set_prefetch(uavx_handle *h, int every) {
+    if (!h || every < 0) return UAVX_ERR_INVALID_ARG;
+    h->prefetch_every = every;
+    h->ex_calls = 0;
+    return UAVX_OK;
+}
+
 int uavx_set_body_rule(uavx_handle *h, const uavx_body_rule *rule) {
     if (!h || !rule) return UAVX_ERR_INVALID_ARG;
     if (!(rule->speed >= 0) || rule->period < 1 || (rule->period & (rule->period - 1)) != 0)
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_set_body_rule: speed must be >= 0 and period a power of two");
     h->rule = *rule;
     apply_body_rule(h);
+    h->p.world_version++;
     return UAVX_OK;
 }
 
@@ -1662,6 +1793,7 @@ int uavx_set_curriculum(uavx_handle *h, const uavx_level *levels, int32_t n_leve
     }
     hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), h->levels_dev, h->levels);
     UAVX_HIP(h, hipGetLastError());
+    h->p.world_version++;
     h->p.n_levels = n_levels;
     h->p.level_lo = n_levels > 0 ? level_lo : -1;
     h->p.level_hi = n_levels > 0 ? level_hi : -1;
@@ -1820,7 +1952,22 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.ended = a->ended; x.truncated = a->truncated;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
+    // auto-resetting call: draw the layouts of the next episodes BESIDE the step launch (side stream, forked after the
+    // work already queued on `stream`, joined back before this call returns control of `stream`; capturable)
+    const bool resets = a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0;
+    x.use_stage = (h->prefetch_every > 0 && resets) ? 1 : 0;
+    const bool stage = x.use_stage && (h->ex_calls++ % (uint64_t)h->prefetch_every) == 0;
+    if (stage) {
+        UAVX_HIP(h, hipEventRecord(h->ev_fork, st));
+        UAVX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        dispatch(h, PrefetchLaunch{h, grid, h->side, x.seed_lo, x.seed_hi});
+        UAVX_HIP(h, hipGetLastError());
+    }
     dispatch(h, StepExLaunch{h, grid, st, x, a});
+    if (stage) {
+        UAVX_HIP(h, hipEventRecord(h->ev_join, h->side));
+        UAVX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    }
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }

@@ -239,6 +239,17 @@ typedef struct {
  * per-env episode statistics (also by uavx_reset). */
 int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
 
+/* Pre-drawn layouts (default: every = 16 for handles with 8 or more slots per env, learners + bodies; off below that,
+ * where drawing inside the step launch is cheap).  The start / target layout of an env's next episode depends only on
+ * (seed, global env id, episode index, level rule), so every `every`-th uavx_step_ex call with an auto-reset policy or a
+ * step cap also queues a kernel on a side stream of the handle -- forked after the work already in `stream`, joined back
+ * into `stream` before the call returns, capturable in a hipGraph -- that draws the layouts of the episodes that will
+ * start next; a step launch then re-initialises an env with 16-byte copies instead of running the serial accept / reject
+ * chain of MUW:127-153 on one wavefront while the rest of the chip waits for it (profiles/r02_ab_notes.md).  A layout parked
+ * for another seed / world / level, or an episode that ends before the next side launch, simply misses and is drawn in the
+ * step launch as before: results are identical either way.  every = 0 switches the side kernel off. */
+int uavx_set_prefetch(uavx_handle *h, int every);
+
 /* Per-env statistics over the episodes ended so far (by auto-reset or uavx_reset):
  * counts  [E*4] uint32 = episodes, sum of steps, sum of target_reach_count, sum of collision_count
  * returns [E*2] float32 = sum of agent-0 returns (test_sac_multi.py:106 `score`),

@@ -85,7 +85,8 @@ LEVELS = [dict(x_size=24.0, y_size=24.0, collider_radius=0.5, d_sense=8.0, n_act
           dict(x_size=40.0, y_size=40.0, collider_radius=1.0, d_sense=15.0, n_active=8, b_active=16)]
 
 
-def test_config5_combined_vs_oracle(amd, oracle_mod):
+@pytest.mark.parametrize("prefetch", [16, 1, 0])
+def test_config5_combined_vs_oracle(amd, oracle_mod, prefetch):
     """BASELINE configs[4] put together at a size the oracle follows: 8 learners + 16 scripted bodies, randomized-reset
     curriculum (per-env box / d_sense / collider / active counts drawn at every auto-reset), uavx_step_ex with polar
     actions, all-done auto-reset and a step cap, observations written zero-copy into DeviceReplay."""
@@ -98,6 +99,7 @@ def test_config5_combined_vs_oracle(amd, oracle_mod):
     kw = dict(num_agents=L, num_bodies=B, body_speed=2.0, body_period=16, body_seed=3)
     env = amd.BatchedMultiUAVWorld2D(E, seed=21, env_offset=7, **kw)
     orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.set_prefetch(prefetch)   # pre-drawn layouts on a side stream vs. drawing inside the step launch: same results
     env.set_curriculum(small, lo=0, hi=1)
     orc.set_curriculum(small, lo=0, hi=1)
     mem = DeviceReplay(env, horizon=24)

@@ -52,12 +52,16 @@ def test_polar_conversion_matches_the_trainers_formula(amd, oracle_mod):
 
 
 @pytest.mark.parametrize("policy,code,cap,n", [("agent0_done", 1, 0, 4), ("all_done", 2, 90, 4), (None, 0, 40, 8),
-                                                 ("agent0_done", 1, 55, 5), ("all_done", 2, 70, 1)])
+                                                 ("agent0_done", 1, 55, 5), ("all_done", 2, 70, 1), ("agent0_done", 1, 1, 4),
+                                                 ("agent0_done", 1, 3, 24), ("noprefetch", 1, 30, 4)])
 def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, policy, code, cap, n):
     import torch
     E = 1536
     kw = dict(x_size=26.0, y_size=26.0, num_agents=n, d_sense=9.0)
     env = amd.BatchedMultiUAVWorld2D(E, seed=77, env_offset=5, **kw)
+    if policy == "noprefetch":   # every reset drawn inside the step launch (the pre-drawn layouts switched off)
+        env.set_prefetch(0)
+        policy = "agent0_done"
     orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
     env.reset()
     orc.reset_philox(77, env_offset=5)

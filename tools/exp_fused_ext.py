@@ -11,8 +11,11 @@ g = torch.Generator(device=dev).manual_seed(1)
 ring = (torch.rand((R, E, N, 2), generator=g, device=dev) * 2 - 1)
 cart = ring * 10
 
+PREFETCH = int(os.environ.get("UAVX_PREFETCH", "16"))
+
 def timeit(fn, levels=False):
     env = BatchedMultiUAVWorld2D(E, num_agents=N, num_bodies=B, device=dev)
+    env.set_prefetch(PREFETCH)
     if levels:
         env.set_curriculum([dict(x_size=40, y_size=40, collider_radius=1.0, d_sense=15), dict(x_size=50, y_size=50, collider_radius=1.0, d_sense=15)], lo=0, hi=1)
     env.reset()
