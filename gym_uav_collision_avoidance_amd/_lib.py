@@ -80,7 +80,7 @@ class UWStepArgs(ctypes.Structure):  # uavx_uw_step_args
                 ("auto_reset", ctypes.c_int32), ("step_cap", ctypes.c_uint32), ("track_returns", ctypes.c_int32),
                 ("reserved", ctypes.c_int32), ("seed", ctypes.c_uint64), ("obs", ctypes.c_void_p),
                 ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("info_distance", ctypes.c_void_p),
-                ("reset_mask", ctypes.c_void_p)]
+                ("reset_mask", ctypes.c_void_p), ("ended", ctypes.c_void_p), ("truncated", ctypes.c_void_p)]
 
 
 _lib = None

@@ -590,14 +590,16 @@ class BatchedUAVWorld2D(_Base):
         a, code = self._actions_arg(actions, (self.num_envs, 2))
         obs = self._next_obs_buf()
         if not hasattr(self, "_reset_mask"):
-            self._reset_mask = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+            self._reset_mask = torch.zeros((3, self.num_envs), dtype=torch.uint8, device=self.device)
+        m = self._reset_mask
         args = _lib.UWStepArgs(a.data_ptr(), code, _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN,
                                int(bool(auto_reset)), int(step_cap), int(bool(track_returns)), 0, self.seed,
                                obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(), self._info.data_ptr(),
-                               self._reset_mask.data_ptr())
+                               m[0].data_ptr(), m[1].data_ptr(), m[2].data_ptr())
         _lib.check(self._L.uavx_uw_step_ex(self._h, ctypes.byref(args), self._stream()), self._h, uw=True)
-        return obs, self._rew, self._done.view(torch.bool), {"distance": self._info,
-                                                             "reset_mask": self._reset_mask.view(torch.bool)}
+        mb = m.view(torch.bool)
+        return obs, self._rew, self._done.view(torch.bool), {"distance": self._info, "reset_mask": mb[0], "ended": mb[1],
+                                                             "truncated": mb[2]}
 
     def episode_stats(self):
         c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)

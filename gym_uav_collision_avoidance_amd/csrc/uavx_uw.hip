@@ -50,7 +50,7 @@ struct UwParams {
 struct UwExtra {
     int action_mode, auto_reset, track_returns;
     uint32_t step_cap, seed_lo, seed_hi;
-    uint8_t *reset_mask;
+    uint8_t *reset_mask, *ended, *truncated;
 };
 
 // UW:88-97 in float32
@@ -206,6 +206,8 @@ __global__ __launch_bounds__(kBlock) void uw_step_ex_kernel(UwParams p, UwExtra 
             done_out[e] = 0;
             if (info_out) info_out[e] = s.init_d;
             if (x.reset_mask) x.reset_mask[e] = 1;
+            if (x.ended) x.ended[e] = 0;
+            if (x.truncated) x.truncated[e] = 0;
         } else {
             uw_load(p, e, s);
             const uint32_t flags_in = s.flags;
@@ -227,7 +229,10 @@ __global__ __launch_bounds__(kBlock) void uw_step_ex_kernel(UwParams p, UwExtra 
             if (info_out) info_out[e] = dist;
             uw_store(p, e, s, flags_in);
             steps += 1;                                                      // UW:170
-            const bool ended = (x.auto_reset && dn) || (x.step_cap != 0 && steps >= x.step_cap);
+            const bool terminal = x.auto_reset && dn;                                 // test_sac.py:106-109
+            const bool ended = terminal || (x.step_cap != 0 && steps >= x.step_cap);   // :17
+            if (x.ended) x.ended[e] = ended ? 1 : 0;
+            if (x.truncated) x.truncated[e] = (ended && !terminal) ? 1 : 0;
             uint4 out = rec;
             out.y = (rec.y & ~kUwPending) | (ended ? kUwPending : 0u);
             if (x.track_returns) out.z = __float_as_uint(__uint_as_float(rec.z) + rew);   // test_sac.py:98
@@ -503,7 +508,7 @@ int uavx_uw_step_ex(uavx_uw_handle *h, const uavx_uw_step_args *a, void *stream)
     UwExtra x;
     x.action_mode = a->action_mode; x.auto_reset = a->auto_reset; x.track_returns = a->track_returns;
     x.step_cap = a->step_cap; x.seed_lo = (uint32_t)a->seed; x.seed_hi = (uint32_t)(a->seed >> 32);
-    x.reset_mask = a->reset_mask;
+    x.reset_mask = a->reset_mask; x.ended = a->ended; x.truncated = a->truncated;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (a->action_dtype == UAVX_F64)
         hipLaunchKernelGGL((uw_step_ex_kernel<true>), env_grid(h), dim3(kBlock), 0, st, h->p, x, a->actions,

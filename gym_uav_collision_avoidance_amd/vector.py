@@ -15,7 +15,8 @@ per-agent list, MUW:233) and by the batch size:
     test_sac_multi.py:112; "all_done" the evaluation rule, :161; None never) or at `step_cap` (:17,67), in the
     step AFTER the one that returned the terminal transition (EnvPool order, not gym's same-step order): the
     terminal observation is therefore simply the `obs` of that step, and the re-initialised row comes back
-    with reward 0, done False and info["reset_mask"][e] True;
+    with reward 0, done False and info["reset_mask"][e] True; the step that ENDS an episode carries
+    info["ended"][e] and, when the step cap alone ended it, info["truncated"][e] (a time-limit cut, not a terminal state);
   * `info` is one dict of [E] device tensors, not a tuple of E dicts.
 """
 import numpy as np

@@ -324,6 +324,10 @@ typedef struct {
     uint8_t *done;         /* [E] */
     float *info_distance;  /* [E] or NULL */
     uint8_t *reset_mask;   /* [E] or NULL */
+    /* ABI version 2 (appended), as in uavx_step_args: ended[e] = 1 where this call's step ended the episode (done with
+     * auto_reset, or the step cap), truncated[e] = 1 where the step cap alone did (done was 0).  Either may be NULL. */
+    uint8_t *ended;        /* [E] or NULL */
+    uint8_t *truncated;    /* [E] or NULL */
 } uavx_uw_step_args;
 int uavx_uw_step_ex(uavx_uw_handle *h, const uavx_uw_step_args *args, void *stream);
 /* counts [E*4] uint32 = episodes, sum of steps, episodes that ended at the target (UW:159), reserved;

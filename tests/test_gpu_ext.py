@@ -292,7 +292,7 @@ def test_uw_entry_points_reject_misaligned_buffers(amd):
     assert L.uavx_uw_step(h, act.data_ptr() + 8, _lib.F64, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), None, st) == -1
     assert L.uavx_uw_observe(h, obs.data_ptr() + 8, st) == -1
     assert L.uavx_uw_reset(h, None, 0, obs.data_ptr() + 4, st) == -1
-    args = _lib.UWStepArgs(act.data_ptr(), _lib.F32, 0, 0, 0, 0, 0, 0, obs.data_ptr() + 4, rew.data_ptr(), done.data_ptr(), None, None)
+    args = _lib.UWStepArgs(act.data_ptr(), _lib.F32, 0, 0, 0, 0, 0, 0, obs.data_ptr() + 4, rew.data_ptr(), done.data_ptr(), None, None, None, None)
     assert L.uavx_uw_step_ex(h, ctypes.byref(args), st) == -1
     assert b"aligned" in L.uavx_uw_last_error(h)
     env.close()

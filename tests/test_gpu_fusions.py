@@ -391,6 +391,10 @@ def test_uw_step_ex_auto_reset_vs_oracle(amd, oracle_mod, polar, cap):
         ctx = f"step {t}"
         np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm, err_msg=ctx)
         np.testing.assert_array_equal(_np(dg).astype(np.uint8), do, err_msg=ctx)
+        # ended / truncated of the ending call: the oracle's `pending` is "ended"; truncated = ended without a done
+        stepped = rm == 0
+        np.testing.assert_array_equal(_np(info["ended"]).astype(np.uint8), orc.pending * stepped, err_msg=ctx)
+        np.testing.assert_array_equal(_np(info["truncated"]).astype(np.uint8), orc.pending * stepped * (do == 0), err_msg=ctx)
         resets += int(rm.sum())
         st = env.get_state()
         np.testing.assert_array_equal(_np(st["loc"]), orc.loc.astype(np.float32), err_msg=ctx)
