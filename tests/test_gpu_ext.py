@@ -241,6 +241,32 @@ def test_config5_full_size_properties(amd):
     assert len(torch.unique(lv)) == 3
 
 
+def test_static_obstacles_single_uav(amd, oracle_mod):
+    """BASELINE configs[0] / [1] name "1 UAV + static obstacles": a body with speed 0 is a static obstacle.  One learner among
+    12 of them: the records never move, the learner senses / collides with them exactly as the oracle says."""
+    import torch
+    E, L, B = 4096, 1, 12
+    kw = dict(num_agents=L, num_bodies=B, body_speed=0.0, body_period=4, x_size=24.0, y_size=24.0, d_sense=8.0)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=6, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.reset(); orc.reset_philox(6)
+    start = _np(env.get_bodies()).copy()
+    rng = np.random.default_rng(2)
+    hits = 0
+    for t in range(80):
+        act = _seek_actions(orc, rng, noise=0.5)
+        o_g, r_g, d_g, _ = env.step(torch.from_numpy(act).to(env.device))
+        o_o, r_o, d_o = orc.step(act)
+        np.testing.assert_array_equal(_np(d_g).astype(np.uint8), d_o)
+        _compare_state(env, orc, f"step {t}")
+        assert obs_err(_np(o_g), o_o) <= TOL and float(np.abs(_np(r_g) - r_o).max()) <= TOL
+        hits += int((r_o == -2).sum())
+    now = _np(env.get_bodies())
+    np.testing.assert_array_equal(now[..., :2], start[..., :2])      # static: positions untouched (waypoints re-drawn, unused)
+    assert hits > 0
+    env.close()
+
+
 def test_extension_argument_checks(amd):
     """Error behaviour of the new entry points and of caller-owned output buffers (no kernel must run on a bad call)."""
     import torch
