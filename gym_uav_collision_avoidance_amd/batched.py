@@ -324,7 +324,7 @@ class BatchedMultiUAVWorld2D(_Base):
                  "all_done": _lib.RESET_ALL_DONE}
 
     def step_ex(self, actions, evaluate=False, polar=False, auto_reset=None, step_cap=0, track_returns=True,
-                out=None):
+                out=None, flags_out=None):
         """env.step plus what the reference's trainer loops do around it, in the same launch:
           polar=True       actions are policy outputs a in [-1,1]^2, converted like test_sac_multi.py:77-80
           auto_reset       "agent0_done" (test_sac_multi.py:112) / "all_done" (:116,161) / None; step_cap (:17,67)
@@ -333,7 +333,9 @@ class BatchedMultiUAVWorld2D(_Base):
         is re-initialised by the NEXT call instead of being stepped (that call's reset_mask[e] is True,
         reward 0, done False).  Returns (obs, rew, done, info) with [E] bool tensors info["reset_mask"],
         info["ended"] (this call ended the env's episode) and info["truncated"] (it ended by the step cap alone: a
-        time-limit cut to bootstrap through, not a terminal state)."""
+        time-limit cut to bootstrap through, not a terminal state).
+        out=(obs, rew, done) / flags_out=(reset_mask, ended, truncated): caller-owned tensors the launch writes instead
+        of the env's own buffers (DeviceReplay hands in slots of its ring: nothing is copied afterwards)."""
         fast = (out is None and type(actions) is torch.Tensor and actions.shape == self._act_shape
                 and actions.is_contiguous() and actions.device == self.device and actions.dtype in _TORCH_DT)
         if fast:
@@ -357,13 +359,20 @@ class BatchedMultiUAVWorld2D(_Base):
             self._reset_mask = torch.zeros((3, self.num_envs), dtype=torch.uint8, device=self.device)
             self._reset_mask_bool = self._reset_mask.view(torch.bool)
             self._ex_args = _lib.StepArgs()
-            self._ex_args.reset_mask = self._reset_mask[0].data_ptr()
-            self._ex_args.ended = self._reset_mask[1].data_ptr()
-            self._ex_args.truncated = self._reset_mask[2].data_ptr()
+            self._flag_ptrs = tuple(self._reset_mask[i].data_ptr() for i in range(3))
             self._ex_ref = ctypes.byref(self._ex_args)
             self._ex_info = {"distance": 0, "reset_mask": self._reset_mask_bool[0], "ended": self._reset_mask_bool[1],
                              "truncated": self._reset_mask_bool[2]}
         args = self._ex_args  # one struct reused across calls: only the fields that change are written
+        info = self._ex_info
+        if flags_out is not None:
+            fl = [self._out(t.view(torch.uint8) if t.dtype == torch.bool else t, (self.num_envs,), torch.uint8, f"flags_out[{i}]")
+                  for i, t in enumerate(flags_out)]
+            args.reset_mask, args.ended, args.truncated = (t.data_ptr() for t in fl)
+            info = {"distance": 0, "reset_mask": fl[0].view(torch.bool), "ended": fl[1].view(torch.bool),
+                    "truncated": fl[2].view(torch.bool)}
+        else:
+            args.reset_mask, args.ended, args.truncated = self._flag_ptrs
         args.actions, args.action_dtype = a.data_ptr(), code
         args.action_mode = _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN
         args.evaluate = 1 if evaluate else 0
@@ -373,7 +382,7 @@ class BatchedMultiUAVWorld2D(_Base):
         rc = self._L.uavx_step_ex(self._h, self._ex_ref, self._stream())
         if rc:
             _lib.check(rc, self._h)
-        return obs, rew, done_bool, self._ex_info
+        return obs, rew, done_bool, info
 
     def episode_stats(self):
         """Statistics over the episodes ended so far (auto-reset or reset()): dict of [E] tensors

@@ -54,10 +54,7 @@ class DeviceReplay:
             self.act[k].copy_(actions)
         nxt = (self.count + 1) % self.L
         obs, rew, done, info = self.env.step_ex(self.act[k], out=(self.obs[nxt], self.rew[k], self.done[k]),
-                                                **step_ex_kwargs)
-        self.skip[k].copy_(info["reset_mask"])
-        self.trunc[k].copy_(info["truncated"])
-        self.ended[k].copy_(info["ended"])
+                                                flags_out=(self.skip[k], self.ended[k], self.trunc[k]), **step_ex_kwargs)
         self.count += 1
         return obs, rew, done, info
 
