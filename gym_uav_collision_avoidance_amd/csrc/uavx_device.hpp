@@ -114,6 +114,22 @@ __device__ __forceinline__ float atan2_fast(float y, float x) {
     return copysignf(r, y);
 }
 
+// v_max_f64 / v_min_f64 against a wave-uniform limit, as ONE instruction each.  fmax() / fmin() make hipcc canonicalise
+// every operand first (v_max_f64 x, x, x -- also the limits held in scalar registers, again at every use): 20 float64
+// instructions for the 12 clamps of one agent step, and a float64 instruction costs two float32 issue slots.  For
+// non-NaN operands the result is the same; a NaN operand gives the other one back (what the callers count on: they
+// re-poison NaN inputs afterwards).  `lim` must be uniform (kernel argument / literal): it is passed in scalar registers.
+__device__ __forceinline__ double max64u(double x, double lim) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lim));
+    return r;
+}
+__device__ __forceinline__ double min64u(double x, double lim) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lim));
+    return r;
+}
+
 // x / tau, correctly rounded, without the hardware division sequence: with r = RN(1/tau) the
 // Markstein form q0 = RN(x*r), rem = fma(-q0, tau, x) (exact), q = fma(rem, r, q0) returns the IEEE
 // quotient (checked against x/tau on 2.1e9 samples for tau = 0.02 and six other steps; uavx_create
@@ -122,7 +138,7 @@ __device__ __forceinline__ float atan2_fast(float y, float x) {
 // (a NaN turns into a finite value here; axis_update() poisons the result afterwards).
 __device__ __forceinline__ double div_tau(double x, double tau, double rtau, bool recip_ok) {
     if (!recip_ok) return x / tau;
-    x = fmin(fmax(x, -1e300), 1e300);
+    x = min64u(max64u(x, -1e300), 1e300);
     const double q0 = x * rtau;
     const double rem = fma(-q0, tau, x);
     return fma(rem, rtau, q0);
@@ -135,8 +151,8 @@ __device__ __forceinline__ double div_tau(double x, double tau, double rtau, boo
 __device__ __forceinline__ void axis_update(double a, double tau, double rtau, bool recip_ok, double amax, double vmax,
                                             double &v, float &x) {
     const bool poisoned = __builtin_isunordered(a, v);
-    const double dv = fmin(fmax(div_tau(a - v, tau, rtau, recip_ok), -amax), amax);  // AG:26
-    double nv = fmin(fmax(v + dv * tau, -vmax), vmax);                               // AG:27
+    const double dv = min64u(max64u(div_tau(a - v, tau, rtau, recip_ok), -amax), amax);  // AG:26
+    double nv = min64u(max64u(v + dv * tau, -vmax), vmax);                               // AG:27
     nv = poisoned ? __builtin_nan("") : nv;
     v = nv;
     x = (float)((double)x + v * tau);                                                // AG:28-29 (float32 array += float64 array)
