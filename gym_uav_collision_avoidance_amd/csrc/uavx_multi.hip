@@ -105,7 +105,7 @@ struct MultiParams {
     int n_levels, level_lo, level_hi;
     float4 *body;                 // [E*B] {x, y, wx, wy}
     uint8_t *lvl_cur, *lvl_next;  // [E] level in force / level assigned for the next reset
-    const LevelParams *levels;    // [UAVX_MAX_LEVELS]; entry 0 mirrors the handle's config while no curriculum is installed
+    const LevelParams *levels;    // [UAVX_MAX_LEVELS] device table, read only while a curriculum is installed (n_levels > 0)
     // ---- pre-drawn layouts (uavx_step_ex auto-reset; see prefetch_kernel) ----
     // The layout of an env's NEXT episode is a pure function of (seed, global env, episode index, level rule), so it is
     // drawn ahead of time by a kernel that runs BESIDE the step launch and parked here; the step launch that re-initialises
@@ -216,7 +216,7 @@ using Lds = LdsT<false>;
 template <bool EXT>
 __device__ __forceinline__ WorldLims world_lims(const MultiParams &p, uint32_t flags) {
     WorldLims w;
-    if (EXT) {
+    if (EXT && p.n_levels > 0) {   // uniform: no curriculum installed -> the handle's own world, as in the plain kernels
         const float4 *t = reinterpret_cast<const float4 *>(&p.levels[(flags & kLevelMask) >> kLevelShift]);
         const float4 a = t[0], b = t[1];
         w.lo_x = a.x; w.lo_y = a.y; w.hi_x = a.z; w.hi_y = a.w;
@@ -480,8 +480,9 @@ template <bool MOVE, class LDS>
 __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap &m, LDS &lds, uint32_t flags, bool from_lds,
                                              bool frozen, uint32_t steps, uint32_t ep_draw) {
     const int L = p.N;
-    const LevelParams *lv = &p.levels[(flags & kLevelMask) >> kLevelShift];
-    const int b_active = m.active ? lv->b_active : 0;
+    const bool leveled = p.n_levels > 0;
+    const LevelParams *lv = &p.levels[(flags & kLevelMask) >> kLevelShift];   // read only when a curriculum is installed
+    const int b_active = m.active ? (leveled ? lv->b_active : p.B) : 0;
 #pragma unroll 1
     for (int k = 0; k < p.kb; k++) {
         const int b = k * L + m.i;
@@ -496,7 +497,8 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
             if (steps != 0u && (steps & (uint32_t)p.body_pmask) == 0u) {  // a new waypoint every `period` steps
                 const ResetCandidates c = reset_candidates((uint64_t)p.env_offset + m.e, (uint32_t)(L + b),
                                                            0x80000000u | (steps >> p.body_pshift), ep_draw, p.body_k0,
-                                                           p.body_k1, lv->lox, lv->loy, lv->hix, lv->hiy);
+                                                           p.body_k1, leveled ? lv->lox : p.lox, leveled ? lv->loy : p.loy,
+                                                           leveled ? lv->hix : p.hix, leveled ? lv->hiy : p.hiy);
                 r.z = c.sx; r.w = c.sy;
             }
             const float dx = r.z - r.x, dy = r.w - r.y;
@@ -720,10 +722,13 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
             }
             lvl = min(lvl, (uint32_t)(p.n_levels - 1));
         }
-        const LevelParams *lv = &p.levels[lvl];
-        lox = lv->lox; loy = lv->loy; hix = lv->hix; hiy = lv->hiy;
-        sq2r = lv->sq_two_r;
-        nl = lv->n_active; nb = lv->b_active;
+        nb = p.B;
+        if (p.n_levels > 0) {
+            const LevelParams *lv = &p.levels[lvl];
+            lox = lv->lox; loy = lv->loy; hix = lv->hix; hiy = lv->hiy;
+            sq2r = lv->sq_two_r;
+            nl = lv->n_active; nb = lv->b_active;
+        }
     }
     const bool gl = go && m.i < nl;  // this lane's learner takes part
     ResetCandidates c = {0.f, 0.f, 0.f, 0.f};
@@ -955,8 +960,7 @@ __global__ __launch_bounds__(kWave * W) void step_ex_kernel(MultiParams p, StepE
             bool parked = false;
             if (EXT) {
                 const uint32_t lvl = tag.w & 0xFFu;
-                const LevelParams *lv = &p.levels[lvl];
-                parked = m.i >= lv->n_active;
+                parked = p.n_levels > 0 && m.i >= p.levels[lvl].n_active;
                 fresh.flags = (lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
                 if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)lvl;
 #pragma unroll 1
@@ -1743,13 +1747,7 @@ int uavx_set_config(uavx_handle *h, const uavx_config *cfg) {
     h->wl = derive_wide_limits(*cfg);
     apply_body_rule(h);
     h->p.world_version++;             // pre-drawn layouts of the old world are stale
-    if (h->ext) {  // EXT kernels read the world from level 0 of the device table
-        UAVX_ENTER(h);
-        h->levels.l[0] = make_level(*cfg, nullptr, h->p.N, h->p.B);
-        hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);
-        UAVX_HIP(h, hipGetLastError());
-    }
-    return UAVX_OK;
+    return UAVX_OK;   // host-only: without a curriculum the EXT kernels take the world from their arguments too
 }
 
 int uavx_num_bodies(const uavx_handle *h) { return h ? h->p.B : -1; }
