@@ -241,6 +241,54 @@ def test_config5_full_size_properties(amd):
     assert len(torch.unique(lv)) == 3
 
 
+def test_randomized_extension_shapes(amd, oracle_mod):
+    """Differential run over odd shapes: learner / body counts from 1+0 to 64 slots, one env up to a few hundred, every
+    waypoint period, random level tables, small step caps (resets every few calls), all three layout-prefetch cadences."""
+    import torch
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 63), (63, 1), (64, 0), (3, 61), (2, 1), (7, 9), (16, 16), (31, 33), (5, 0), (1, 1), (9, 23), (12, 4)]
+    for case, (L, B) in enumerate(shapes):
+        E = int(rng.choice([1, 2, 7, 65, 130, 257]))
+        period = int(rng.choice([1, 2, 8, 64]))
+        box = float(rng.uniform(4.0, 9.0) * np.sqrt(L + B) + 6.0)
+        kw = dict(num_agents=L, num_bodies=B, body_speed=float(rng.uniform(0.0, 9.0)), body_period=period, body_seed=case,
+                  x_size=box, y_size=box * float(rng.uniform(0.7, 1.0)), d_sense=float(rng.uniform(4.0, 16.0)),
+                  collider_radius=float(rng.uniform(0.2, 0.9)))
+        env = amd.BatchedMultiUAVWorld2D(E, seed=case, env_offset=3 * case, **kw)
+        orc = oracle_mod.OracleMulti(num_envs=E, nthreads=4, **kw)
+        nlev = int(rng.integers(0, 4))
+        if nlev:
+            levels = [dict(x_size=box * float(rng.uniform(0.7, 1.1)), y_size=box * float(rng.uniform(0.6, 1.0)),
+                           collider_radius=float(rng.uniform(0.2, 0.8)), d_sense=float(rng.uniform(3.0, 14.0)),
+                           n_active=int(rng.integers(1, L + 1)), b_active=int(rng.integers(0, B + 1))) for _ in range(nlev)]
+            lo = int(rng.integers(-1, nlev))
+            hi = int(rng.integers(max(lo, 0), nlev))
+            env.set_curriculum(levels, lo=lo, hi=hi)
+            orc.set_curriculum(levels, lo=lo, hi=hi)
+            if lo < 0:
+                assign = rng.integers(0, nlev, size=E).astype(np.uint8)
+                env.set_env_levels(assign); orc.set_env_levels(assign)
+        env.set_prefetch(int(rng.choice([0, 1, 3])))
+        cap = int(rng.choice([1, 2, 5, 9]))
+        pol, code = [("agent0_done", 1), ("all_done", 2), (None, 0)][case % 3]
+        env.reset(); orc.reset_philox(case, env_offset=3 * case)
+        ctx = f"case {case}: L{L} B{B} E{E} period {period} levels {nlev} cap {cap} {pol}"
+        _compare_state(env, orc, ctx + " reset")
+        for t in range(14):
+            a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
+            o_g, r_g, d_g, info = env.step_ex(torch.from_numpy(a).to(env.device), polar=True, auto_reset=pol, step_cap=cap,
+                                              evaluate=bool(t % 2))
+            o_o, r_o, d_o, rm, en, tr = orc.step_ex(a, action_mode=1, reset_policy=code, step_cap=cap, evaluate=bool(t % 2),
+                                                    track_returns=True, seed=case, env_offset=3 * case, with_end=True)
+            np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm, err_msg=ctx)
+            np.testing.assert_array_equal(_np(info["ended"]).astype(np.uint8), en, err_msg=ctx)
+            np.testing.assert_array_equal(_np(info["truncated"]).astype(np.uint8), tr, err_msg=ctx)
+            np.testing.assert_array_equal(_np(d_g).astype(np.uint8), d_o, err_msg=ctx)
+            _compare_state(env, orc, f"{ctx} step {t}")
+            assert obs_err(_np(o_g), o_o) <= TOL and float(np.abs(_np(r_g) - r_o).max()) <= TOL, ctx
+        env.close()
+
+
 def test_static_obstacles_single_uav(amd, oracle_mod):
     """BASELINE configs[0] / [1] name "1 UAV + static obstacles": a body with speed 0 is a static obstacle.  One learner among
     12 of them: the records never move, the learner senses / collides with them exactly as the oracle says."""
