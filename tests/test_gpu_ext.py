@@ -241,6 +241,38 @@ def test_config5_full_size_properties(amd):
     assert len(torch.unique(lv)) == 3
 
 
+def test_extension_fixture_replay_on_device(amd):
+    """The committed known-answer fixture of the extension (tests/golden/ext_bodies_levels.npz, produced by the oracle with
+    tests/golden/make_ext_golden.py) replayed through the C ABI without the oracle in the loop."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_ext_golden as g
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "ext_bodies_levels.npz"))
+    env = amd.BatchedMultiUAVWorld2D(g.E, seed=g.SEED, env_offset=g.OFFSET, **g.KW)
+    env.set_curriculum(g.LEVELS, lo=0, hi=1)
+    env.reset()
+    np.testing.assert_array_equal(_np(env.get_bodies()), fx["init_body"])
+    np.testing.assert_array_equal(_np(env.env_levels()), fx["init_level"])
+    np.testing.assert_array_equal(_np(env.get_state()["flags"]), fx["init_flags"])
+    for t in range(g.T):
+        o, r, d, info = env.step_ex(torch.from_numpy(fx["actions"][t]).to(env.device), polar=True, auto_reset="all_done",
+                                    step_cap=g.CAP, evaluate=True)
+        for key, got in (("done", d), ("reset_mask", info["reset_mask"]), ("ended", info["ended"]), ("truncated", info["truncated"])):
+            np.testing.assert_array_equal(_np(got).astype(np.uint8), fx[key][t], err_msg=f"{key} step {t}")
+        st = env.get_state()
+        on = (fx["flags"][t] & 32) == 0
+        np.testing.assert_array_equal(_np(st["flags"]), fx["flags"][t])
+        np.testing.assert_array_equal(_np(st["loc"])[on], fx["loc"][t].astype(np.float32)[on])
+        np.testing.assert_array_equal(_np(st["vel"])[on], fx["vel"][t][on])
+        np.testing.assert_array_equal(_np(st["counters"]), fx["counters"][t].astype(np.int32))
+        np.testing.assert_array_equal(_np(env.get_bodies()), fx["body"][t])
+        np.testing.assert_array_equal(_np(env.env_levels()), fx["level"][t])
+        assert obs_err(_np(o), fx["obs"][t]) <= TOL and float(np.abs(_np(r) - fx["rew"][t]).max()) <= TOL
+    env.close()
+
+
 def test_randomized_extension_shapes(amd, oracle_mod):
     """Differential run over odd shapes: learner / body counts from 1+0 to 64 slots, one env up to a few hundred, every
     waypoint period, random level tables, small step caps (resets every few calls), all three layout-prefetch cadences."""
