@@ -44,7 +44,11 @@ def run():
     return out
 
 
+META = dict(kind="extension", source="oracle/uavx_oracle.c (uavo_*_x): NOT a reference vector, see the module docstring",
+            kw=KW, levels=LEVELS, envs=E, steps=T, seed=SEED, env_offset=OFFSET, step_cap=CAP)
+
 if __name__ == "__main__":
+    import json
     oracle.build()
-    np.savez_compressed(os.path.join(HERE, "ext_bodies_levels.npz"), **run())
+    np.savez_compressed(os.path.join(HERE, "ext_bodies_levels.npz"), meta=np.array(json.dumps(META)), **run())
     print("wrote ext_bodies_levels.npz")
