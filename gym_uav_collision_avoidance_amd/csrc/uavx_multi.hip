@@ -897,8 +897,11 @@ __device__ unsigned int g_stamp_n;
 
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
 // episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
+// Register budget: the re-initialisation path keeps a second agent record live and takes the variant with bodies to 83 VGPRs =
+// 5 wavefronts per SIMD; asking for 6 (<= 80 VGPRs, two dwords spilled on the rare path) matches what its LDS admits:
+// 8 + 16 bodies 23.8 -> 23.2 us.  (The same bound on the N = 8 variant spills in the hot path: 11.8 -> 17.8 us, not applied.)
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+__global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                             int evaluate, float *__restrict__ obs_out,
                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
