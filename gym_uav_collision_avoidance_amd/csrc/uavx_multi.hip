@@ -197,6 +197,21 @@ struct LdsT {
     float theta[kRows];           // heading atan2(vy, vx)
     float obs[kWave * W * UAVX_OBS_DIM];
 };
+// With scripted bodies the neighbour rows alone are 3.8 KB per wavefront; the obs staging tile shares their bytes: it is
+// written after the last read of the rows (one wavefront per workgroup: DS operations execute in issue order), so the
+// workgroup needs 3 840 B instead of 6 400 B and a CU holds 28 wavefronts (the register limit) instead of 25.
+template <>
+struct LdsT<true, 1> {
+    static constexpr int kW = 1;
+    static constexpr int kRows = kExtSlots;
+    union {
+        struct {
+            float4 pos[kRows];
+            float theta[kRows];
+        };
+        float obs[kWave * UAVX_OBS_DIM];
+    };
+};
 // All cross-agent traffic of an env stays inside its workgroup.  With one wavefront per workgroup a compiler-level
 // ordering point is enough (wave_lds_sync); an env that spans two wavefronts needs the workgroup barrier.
 template <int W>
