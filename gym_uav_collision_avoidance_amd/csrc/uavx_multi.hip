@@ -631,8 +631,9 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 }
 
 // One env step per launch (the RL loop's shape: the policy runs between two launches).
+// (with bodies the allocator lands on 65 VGPRs = 7 wavefronts per SIMD; asking for 8 gives 62 without a spill)
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+__global__ __launch_bounds__(kWave * W, EXT ? 8 : 1) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
                                                          float *__restrict__ obs_out, float *__restrict__ rew_out,
                                                          uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
