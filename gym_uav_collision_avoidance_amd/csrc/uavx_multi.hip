@@ -913,11 +913,11 @@ __device__ unsigned int g_stamp_n;
 
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
 // episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
-// Register budget: the re-initialisation path keeps a second agent record live and takes the variant with bodies to 83 VGPRs =
-// 5 wavefronts per SIMD; asking for 6 (<= 80 VGPRs, two dwords spilled on the rare path) matches what its LDS admits:
-// 8 + 16 bodies 23.8 -> 23.2 us.  (The same bound on the N = 8 variant spills in the hot path: 11.8 -> 17.8 us, not applied.)
+// Register budget (profiles/r02_ab_notes.md): one agent record instead of three and the statistics fold read back at the end
+// took the variant with bodies from 83 to 72 VGPRs and the N = 8 one from 89 to 79; with bodies a bound of 7 wavefronts
+// per SIMD is kept (the same bound on the N = 8 variant spills in its hot path: 11.3 -> 16.1 us, not applied).
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+__global__ __launch_bounds__(kWave * W, EXT ? 7 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                             int evaluate, float *__restrict__ obs_out,
                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
@@ -938,9 +938,8 @@ __global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiPa
     if (m.active) rec = p.env_rec[m.e];
     const uint32_t wave_count = p.wave_steps[blockIdx.x];
     __builtin_amdgcn_sched_barrier(0);
-    AgentRegs ld = {};
     if (m.active) {
-        load_agent(p, m.a, ld);
+        load_agent(p, m.a, s);
         load_action<ACT64>(actions, m.a, ax, ay);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -948,20 +947,16 @@ __global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiPa
     const uint32_t episode = rec.y & ~kRecEnded;
     uint32_t steps_v = wave_count - rec.x;
     float2 run = make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w));
-    AgentRegs fresh = {};
-    EpisodeFold fold = {};
-    const uint32_t ended_steps = steps_v;
-    const float2 ended_run = run;
+    // Register budget (the variants with 8 agents / bodies sit at the 64-VGPR edge of 8 wavefronts per SIMD): a
+    // re-initialised env's record is written straight over the loaded one (`s`), and what the statistics fold needs is
+    // read back from `rec` and memory at the END of the launch, by the (rare) lanes that need it.
     const bool wave_resets = group_any<W>(do_reset);   // uniform over the workgroup
     STAMP(1);
     if (wave_resets) {  // wave-uniform: at least one env of this wave starts a new episode
         // A wave that re-initialises an env has a few hundred more instructions to issue than its three SIMD
         // mates and would finish last (launch time = slowest wave): let it issue ahead of them for the rest
-        // of its life; the mates lose only issue slots they had to spare.  The statistics words are
-        // requested here and consumed after the step (fold_store at the end): their round trip overlaps the
-        // step arithmetic.
+        // of its life; the mates lose only issue slots they had to spare.
         __builtin_amdgcn_s_setprio(3);
-        if (do_reset && m.i == 0) fold = fold_load(p, m.e);
         // the layout was normally drawn ahead of time by prefetch_kernel (16-byte copies); only a miss -- first use, a
         // changed seed / world, an episode shorter than one call -- draws here
         bool hit = false;
@@ -971,16 +966,16 @@ __global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiPa
             hit = stage_hit(tag, stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
         }
         if (group_any<W>(do_reset && !hit))
-            reset_envs_wave<NT, EXT>(p, m, lds, do_reset && !hit, episode, x.seed_lo, x.seed_hi, fresh, p.body, p.lvl_cur);
+            reset_envs_wave<NT, EXT>(p, m, lds, do_reset && !hit, episode, x.seed_lo, x.seed_hi, s, p.body, p.lvl_cur);
         if (hit) {
             const float4 st = p.stage_agent[m.a];
-            fresh.x = st.x; fresh.y = st.y; fresh.tx = st.z; fresh.ty = st.w;
-            fresh.vx = 0.0; fresh.vy = 0.0; fresh.flags = 0;                 // MUW:120-123
+            s.x = st.x; s.y = st.y; s.tx = st.z; s.ty = st.w;
+            s.vx = 0.0; s.vy = 0.0; s.flags = 0;                 // MUW:120-123
             bool parked = false;
             if (EXT) {
                 const uint32_t lvl = tag.w & 0xFFu;
                 parked = p.n_levels > 0 && m.i >= p.levels[lvl].n_active;
-                fresh.flags = (lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
+                s.flags = (lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
                 if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)lvl;
 #pragma unroll 1
                 for (int k = 0; k < p.kb; k++) {   // the bodies' records: staged -> live, and into the env's LDS rows
@@ -992,16 +987,15 @@ __global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiPa
                     }
                 }
             }
-            fresh.init_d = fresh.prev_d = parked ? INFINITY : norm32(fresh.tx - fresh.x, fresh.ty - fresh.y);  // MUW:154-155
+            s.init_d = s.prev_d = parked ? INFINITY : norm32(s.tx - s.x, s.ty - s.y);  // MUW:154-155
         }
         if (do_reset) {
-            p.goal[m.a] = Goal{fresh.tx, fresh.ty, fresh.init_d, fresh.flags};
+            p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, s.flags};
             steps_v = 0;                                           // MUW:166
             run = make_float2(0.f, 0.f);
         }
     }
     STAMP(2);
-    s = do_reset ? fresh : ld;
     const uint32_t flags_in = s.flags;
     STAMP(3);
     if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
@@ -1050,7 +1044,7 @@ __global__ __launch_bounds__(kWave * W, EXT ? 6 : 1) void step_ex_kernel(MultiPa
             if (x.truncated) x.truncated[m.e] = (ended && !terminal) ? 1 : 0;
             uint4 out = rec;
             if (do_reset) {  // fold the ended episode, start the new one: steps == 0 after this launch (MUW:166)
-                fold_store(p, m.e, ended_steps, ended_run, fold);
+                fold_store(p, m.e, wave_count - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold_load(p, m.e));
                 out.x = wave_count + 1u;
                 out.y = episode + 1u;
             }
