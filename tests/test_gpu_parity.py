@@ -356,6 +356,38 @@ def test_full_size_properties(amd):
     assert float(full[0][..., [0, 1, 3, 4, 5, 6, 7, 8, 9]].abs().max()) <= 1.0 + 1e-6  # only the target distance may exceed 1
 
 
+def test_config3_eight_shards_equal_one_batch(amd):
+    """BASELINE configs[3] (262 144 envs x 4 UAVs sharded over 8 GPUs, gather of episode metrics) on ONE GPU: the eight
+    32 768-env shards a rank-r process would own (env_offset = r * 32 768) are run one after the other and must reproduce the
+    single 262 144-env batch exactly -- state, outputs and the gathered [E, 4] metric rows the SR / CR come from.  (The
+    8-process RCCL run itself is the driver's; the gather is covered by the world-2 gloo test and bench.py's 1-rank RCCL path.)"""
+    import torch
+    from gym_uav_collision_avoidance_amd.sharding import shard_range, summarize_metrics
+    total, world, n, T = 262144, 8, 4, 24
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tape = torch.rand((T, total, n, 2), generator=g, device="cuda") * 2 - 1
+
+    def run(count, offset):
+        env = amd.BatchedMultiUAVWorld2D(count, num_agents=n, seed=7, env_offset=offset)
+        env.reset()
+        for t in range(T):
+            obs, rew, done, info = env.step_ex(tape[t, offset:offset + count], polar=True, auto_reset="agent0_done", step_cap=10)
+        out = (obs.clone(), rew.clone(), done.clone(), env.metrics().clone(), env.get_state()["loc"].clone(),
+               {k: v.clone() for k, v in env.episode_stats().items()})
+        env.close()
+        return out
+
+    whole = run(total, 0)
+    shards = [run(*reversed(shard_range(total, world, r))) for r in range(world)]
+    for k in range(5):
+        assert torch.equal(whole[k], torch.cat([s[k] for s in shards], dim=0)), k
+    for key in whole[5]:
+        assert torch.equal(whole[5][key], torch.cat([s[5][key] for s in shards], dim=0)), key
+    gathered = torch.cat([s[3] for s in shards], dim=0)                      # what rank 0 holds after the one gather
+    assert summarize_metrics(gathered, n) == summarize_metrics(whole[3], n)
+    assert int(whole[5]["episodes"].sum()) >= 2 * total                      # the step cap ended every env at least twice
+
+
 # ---------------------------------------------------------------------------------------------------
 # UAVWorld2D
 @pytest.mark.parametrize("name", UW)
