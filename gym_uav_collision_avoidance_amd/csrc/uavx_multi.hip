@@ -192,7 +192,7 @@ struct AgentRegs {
 template <bool EXT, int W = 1>
 struct LdsT {
     static constexpr int kW = W;
-    static constexpr int kRows = EXT ? kExtSlots : kWave * W;
+    static constexpr int kRows = (EXT && kExtSlots > kWave * W) ? kExtSlots : kWave * W;
     float4 pos[kRows];            // {old.x, old.y, new.x, new.y} per neighbour slot
     float theta[kRows];           // heading atan2(vy, vx)
     float obs[kWave * W * UAVX_OBS_DIM];
@@ -633,7 +633,7 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 // One env step per launch (the RL loop's shape: the policy runs between two launches).
 // (with bodies the allocator lands on 65 VGPRs = 7 wavefronts per SIMD; asking for 8 gives 62 without a spill)
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, EXT ? 8 : 1) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 8 : 1) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
                                                          float *__restrict__ obs_out, float *__restrict__ rew_out,
                                                          uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
@@ -917,7 +917,7 @@ __device__ unsigned int g_stamp_n;
 // took the variant with bodies from 83 to 72 VGPRs and the N = 8 one from 89 to 79; with bodies a bound of 7 wavefronts
 // per SIMD is kept (the same bound on the N = 8 variant spills in its hot path: 11.3 -> 16.1 us, not applied).
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, EXT ? 7 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 7 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                             int evaluate, float *__restrict__ obs_out,
                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
@@ -1416,7 +1416,14 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // W wavefronts per workgroup (runtime-N path only).  dispatch() calls l.run<NT, EXT, W>() for the handle's variant.
 template <class L>
 void dispatch(const uavx_handle *h, const L &l) {
-    if (h->ext) return l.template run<0, true, 1>();
+    if (h->ext) {   // bodies pin W = 1 (uavx_create); a curriculum alone keeps the mapping the agent count selected
+        switch (h->gw) {
+            case 2: return l.template run<0, true, 2>();
+            case 3: return l.template run<0, true, 3>();
+            case 4: return l.template run<0, true, 4>();
+            default: return l.template run<0, true, 1>();
+        }
+    }
     switch (h->p.N) {
         case 1: return l.template run<1, false, 1>();
         case 2: return l.template run<2, false, 1>();

@@ -278,7 +278,8 @@ def test_randomized_extension_shapes(amd, oracle_mod):
     waypoint period, random level tables, small step caps (resets every few calls), all three layout-prefetch cadences."""
     import torch
     rng = np.random.default_rng(2024)
-    shapes = [(1, 63), (63, 1), (64, 0), (3, 61), (2, 1), (7, 9), (16, 16), (31, 33), (5, 0), (1, 1), (9, 23), (12, 4)]
+    shapes = [(1, 63), (63, 1), (64, 0), (3, 61), (2, 1), (7, 9), (16, 16), (31, 33), (5, 0), (1, 1), (9, 23), (12, 4),
+              (24, 0), (11, 0), (13, 0), (48, 0), (22, 0)]   # the last five: agent counts on multi-wavefront workgroups
     for case, (L, B) in enumerate(shapes):
         E = int(rng.choice([1, 2, 7, 65, 130, 257]))
         period = int(rng.choice([1, 2, 8, 64]))
@@ -288,7 +289,7 @@ def test_randomized_extension_shapes(amd, oracle_mod):
                   collider_radius=float(rng.uniform(0.2, 0.9)))
         env = amd.BatchedMultiUAVWorld2D(E, seed=case, env_offset=3 * case, **kw)
         orc = oracle_mod.OracleMulti(num_envs=E, nthreads=4, **kw)
-        nlev = int(rng.integers(0, 4))
+        nlev = int(rng.integers(0, 4)) if B or case < 12 else int(rng.integers(1, 4))   # B == 0 needs levels to be an extension handle
         if nlev:
             levels = [dict(x_size=box * float(rng.uniform(0.7, 1.1)), y_size=box * float(rng.uniform(0.6, 1.0)),
                            collider_radius=float(rng.uniform(0.2, 0.8)), d_sense=float(rng.uniform(3.0, 14.0)),

@@ -295,9 +295,10 @@ def test_multi_goal_reaching_batch(amd, oracle_mod):
     env.close()
 
 
-def test_step_k_equals_k_steps(amd):
+@pytest.mark.parametrize("n,E", [(4, 1500), (24, 333), (13, 200), (7, 77)])   # compile-time N, multi-wavefront workgroups, runtime N
+def test_step_k_equals_k_steps(amd, n, E):
     import torch
-    E, n, K = 1500, 4, 9
+    K = 9
     a = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=3)
     b = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=3)
     a.reset(); b.reset()
