@@ -1918,9 +1918,9 @@ int uavx_step_k(uavx_handle *h, int k, const void *actions, int action_dtype, in
     if (k < 1) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_k: k < 1");
     if (action_dtype != UAVX_F32 && action_dtype != UAVX_F64)
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: action_dtype must be UAVX_F32 or UAVX_F64");
-    if ((reinterpret_cast<uintptr_t>(obs) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) ||
+    if ((reinterpret_cast<uintptr_t>(obs) & 15u) || (reinterpret_cast<uintptr_t>(actions) & (action_dtype == UAVX_F64 ? 15u : 7u)) ||
         (reinterpret_cast<uintptr_t>(rew) & 3u))
-        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: obs/actions must be 16-byte aligned, rew 4-byte aligned");
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step: obs must be 16-byte aligned, actions 8 (float32) / 16 (float64), rew 4");
     UAVX_ENTER(h);
     if (h->wide) {
         if (k != 1) return fail(h, UAVX_ERR_UNSUPPORTED, "uavx_step_k: k > 1 is not available for float64-position episodes");
@@ -1950,9 +1950,9 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown action_mode");
     if (a->reset_policy < UAVX_RESET_NEVER || a->reset_policy > UAVX_RESET_ALL_DONE)
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown reset_policy");
-    if ((reinterpret_cast<uintptr_t>(a->obs) & 15u) || (reinterpret_cast<uintptr_t>(a->actions) & 15u) ||
+    if ((reinterpret_cast<uintptr_t>(a->obs) & 15u) || (reinterpret_cast<uintptr_t>(a->actions) & (a->action_dtype == UAVX_F64 ? 15u : 7u)) ||
         (reinterpret_cast<uintptr_t>(a->rew) & 3u))
-        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: obs/actions must be 16-byte aligned, rew 4-byte aligned");
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: obs must be 16-byte aligned, actions 8 (float32) / 16 (float64), rew 4");
     UAVX_ENTER(h);
     if (h->wide) {
         if (a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0)
