@@ -307,12 +307,28 @@ def test_randomized_extension_shapes(amd, oracle_mod):
         env.reset(); orc.reset_philox(case, env_offset=3 * case)
         ctx = f"case {case}: L{L} B{B} E{E} period {period} levels {nlev} cap {cap} {pol}"
         _compare_state(env, orc, ctx + " reset")
-        for t in range(14):
+        seed = case
+        for t in range(16):
+            if t == 5:      # an explicit masked reset in the middle (folds the running episodes, draws fresh layouts)
+                mask = rng.random(E) < 0.5
+                env.reset(mask=torch.from_numpy(mask).to(env.device)); orc.reset_philox(seed, mask=mask, env_offset=3 * case)
+                _compare_state(env, orc, ctx + " masked reset")
+            if t == 7:      # state read back and written unchanged: a no-op (level bits, parked flags, counters survive)
+                st = env.get_state()
+                env.set_state(**{k: v for k, v in st.items()})
+                if B:
+                    env.set_bodies(env.get_bodies())
+            if t == 9:      # another seed: layouts parked for the old one must not be used
+                seed = case + 1000
+                env.seed = seed
+            if t == 11 and nlev == 0:   # handle-wide world change (uavx_set_config) under bodies
+                env.set_config(x_size=box * 0.9, d_sense=kw["d_sense"] * 0.8)
+                orc.set_config(x_size=box * 0.9, d_sense=kw["d_sense"] * 0.8)
             a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
             o_g, r_g, d_g, info = env.step_ex(torch.from_numpy(a).to(env.device), polar=True, auto_reset=pol, step_cap=cap,
                                               evaluate=bool(t % 2))
             o_o, r_o, d_o, rm, en, tr = orc.step_ex(a, action_mode=1, reset_policy=code, step_cap=cap, evaluate=bool(t % 2),
-                                                    track_returns=True, seed=case, env_offset=3 * case, with_end=True)
+                                                    track_returns=True, seed=seed, env_offset=3 * case, with_end=True)
             np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm, err_msg=ctx)
             np.testing.assert_array_equal(_np(info["ended"]).astype(np.uint8), en, err_msg=ctx)
             np.testing.assert_array_equal(_np(info["truncated"]).astype(np.uint8), tr, err_msg=ctx)
