@@ -163,7 +163,8 @@ int uavx_set_bodies(uavx_handle *h, const float *records, void *stream);
  *                  window as training progresses;
  *   level_lo <  0: the level assigned to the env with uavx_set_env_levels (default 0).
  * The reference's analogue is building a new env object per world (test_sac_multi_score.py:31-37).  n_levels = 0 removes
- * the table (every env back on uavx_config).  Enqueues one tiny launch on `stream`. */
+ * the table (every env back on uavx_config; follow it with uavx_reset: learners a level had parked stay parked until their
+ * env is re-initialised).  Enqueues one tiny launch on `stream`. */
 typedef struct {
     double x_size, y_size, collider_radius, d_sense;
     int32_t n_active, b_active;
