@@ -377,7 +377,7 @@ def main():
         slots = N + B
         epw = min(64 // N, 192 // slots) if B else 64 // N   # envs per wavefront (uavx_create)
         grid_threads = -(-E // epw) * 64 if args.world == "multi" else -(-E // block) * block
-        traffic = measured_traffic(kernel_name, grid_threads)
+        traffic = measured_traffic(kernel_name, grid_threads)   # step and step_ex kernels have PMC summaries of their own
         ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
         world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
         if args.world == "multi" and E == 65536 and N == 4 and B == 0:

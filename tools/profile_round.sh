@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/prof/<shape>/<pass>/ (run on the GPU box through gpurun), then
 #   python tools/summarize_profiles.py rNN   condenses it into profiles/.
-# usage: tools/profile_round.sh [calib] [ExN[+B] ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8 65536x24
+# usage: tools/profile_round.sh [calib] [ExN[+B][f] ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f
+#        (+B: scripted bodies; trailing f: the fused uavx_step_ex path with polar actions, auto-reset and statistics)
 # Kernel trace and each counter group are separate runs (counter collection serialises and slows kernels); the
 # program itself follows `--` (no env / bash -c hop).  TCC has 4 counter slots per pass, SQ 8.
 set -e
@@ -26,10 +27,11 @@ for arg in "$@"; do
     done
     continue
   fi
-  shape=${arg%%+*}; bodies=0; [[ "$arg" == *+* ]] && bodies=${arg##*+}
+  fused=""; a=$arg; [[ "$a" == *f ]] && { fused="--fused"; a=${a%f}; }
+  shape=${a%%+*}; bodies=0; [[ "$a" == *+* ]] && bodies=${a##*+}
   E=${shape%%x*}; N=${shape##*x}
   d=$OUT/$arg; rm -rf $d; mkdir -p $d
-  BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large"
+  BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large $fused"
   rocprofv3 --output-format csv --kernel-trace --stats -d $d/kt -o run -- python3 bench.py $BARGS --steps 1000 --warmup 100 > $d/kt.log 2>&1
   echo "$arg kt done"
   for p in fetch write tcc_hit tcc_ea sq sq2; do
