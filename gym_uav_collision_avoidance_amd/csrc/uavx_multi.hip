@@ -4,8 +4,10 @@
 // Reference semantics (cited per block): MUW = gym_uav_collision_avoidance/envs/multi_uav_world_2d.py,
 // AG = .../uav_agent.py of dazchi/gym-uav-collision-avoidance.
 //
-// Work mapping.  One LANE per agent, floor(64/N) whole envs per WAVEFRONT (one env per wave at
-// N > 32), so an env never spans two waves and all cross-agent traffic stays inside the wave:
+// Work mapping.  One LANE per agent, floor(64/N) whole envs per WAVEFRONT, one wavefront per workgroup, so that all
+// cross-agent traffic of an env stays inside its wave (agent counts that would leave many lanes of one wavefront idle use
+// workgroups of 2..4 wavefronts instead, pick_group_waves(): an env may then span two waves of ONE workgroup, and the
+// wave-local ordering points below become workgroup barriers):
 //   1. every lane integrates its own agent (float64 velocity, float32 position, AG:23-36) — the
 //      reference's sequential loop over agents (MUW:181) has no real dependency here because an
 //      agent's motion only reads its own state;
@@ -24,10 +26,11 @@
 //   prev_distance (AG:18) is NOT stored: for an agent that is not done it always equals ||target - location||
 //   (AG:33-34, MUW:155,229), so it is recomputed from the loaded position; values a caller pokes in that
 //   break this identity live in prev_ovr[A] behind the PREVD_OVR flag bit (read only when the bit is set).
-//   per wave:  wave_steps[W] (one no-return atomic per launch; env.steps = wave_steps - env_rec.x)
+//   per workgroup: wave_steps[G] (one no-return atomic per launch; env.steps = wave_steps - env_rec.x)
 //   per env:   reach[E] / coll[E] (atomics on the rare events), env_rec[E] (16 B: steps base, episode index,
 //              running returns; touched by reset / step_ex only), episode statistics (fin_*).
-// One wavefront per workgroup, except on the runtime-N path where pick_group_waves() finds that several pack better.
+// BASELINE configs[4] extension (scripted bodies, per-env curriculum levels; EXT kernel variants): see MultiParams and
+// include/uavx.h; lanes stay one per LEARNER there and the bodies are extra rows of the env's LDS neighbour tile.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -135,7 +138,7 @@ struct StepExtra {
 };
 
 struct LaneMap {
-    int lane, wib;   // thread in its workgroup (the lane when the workgroup is one wavefront); unused
+    int lane;        // thread in its workgroup (the lane when the workgroup is one wavefront)
     int i, base;     // agent index in its env, first lane of the env's group
     int rbase, nslots;  // first LDS neighbour row of the env, rows per env (N unless the env has scripted bodies)
     int g;              // env index within the workgroup
@@ -155,7 +158,6 @@ __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     const int N = NT ? NT : p.N;
     const int epw = NT ? (kWave / (NT ? NT : 1)) : p.epw;
     m.lane = threadIdx.x;            // thread in its workgroup (= lane for W == 1)
-    m.wib = 0;
     const uint32_t wave = blockIdx.x;   // workgroup index (= wavefront index for W == 1)
     int g;
     if (NT) {
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 7 : 1) void step_ex_ke
     store_obs_block<NT>(p, m, lds, o, obs_out);
 #ifdef UAVX_STAMPS
     STAMP(5);
-    if (m.lane == 0 && (wave_resets || (blockIdx.x % 64 == 0 && m.wib == 0))) {
+    if (m.lane == 0 && (wave_resets || (blockIdx.x % 64 == 0))) {
         const unsigned int k = atomicAdd(&g_stamp_n, 1u);
         if (k < 4096) {
             for (int t = 0; t < 6; t++) g_stamps[8 * k + t] = stamps[t];
