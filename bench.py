@@ -417,6 +417,16 @@ def main():
             "episode_metrics": summ,
             "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + len(devs)),
         }
+        if world == 1 and K < 500:
+            # A K-step region this short holds one graph replay whose launch latency (~10-15 us) is a visible share of it;
+            # the same kernel over a 1000-step region of its own (not part of `value`) for the steady per-launch time
+            steady = Stepper(step, ring, device, args.mode)
+            steady.prepare(1000)
+            sd = timed_regions(steady, 1000, 3, device, events=True)
+            ks = statistics.median(sd) * 1e-3 / 1000
+            line["roofline_steady"] = {"kernel_us": ks * 1e6, "achieved": bytes_per_launch / ks / 1e9, "frac": bytes_per_launch / ks / 1e9 / HBM_PEAK_GBS,
+                                       "steps": 1000, "note": f"same launch sequence over 1000-step event regions; the {K}-step regions "
+                                       "of the timing contract include one graph-launch latency each"}
         if world == 1:
             line["latency_us"] = {"single_step_launch_to_done": single_step_latency(step, ring, device),
                                   "kernel": kernel_s * 1e6,
