@@ -33,9 +33,11 @@ for arg in "$@"; do
   d=$OUT/$arg; rm -rf $d; mkdir -p $d
   BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large $fused"
   rocprofv3 --output-format csv --kernel-trace --stats -d $d/kt -o run -- python3 bench.py $BARGS --steps 1000 --warmup 100 > $d/kt.log 2>&1
+  find $d/kt -name "*kernel_trace.csv" -delete; find $d/kt -name "*agent_info.csv" -delete   # keep the stats summary only (64 MiB merge limit)
   echo "$arg kt done"
   for p in fetch write tcc_hit tcc_ea sq sq2; do
     rocprofv3 --output-format csv --kernel-trace --pmc ${PASS[$p]} -d $d/$p -o run -- python3 bench.py $BARGS --steps 100 --warmup 20 --repeats 2 --mode launch > $d/$p.log 2>&1
+    find $d/$p -name "*kernel_trace.csv" -delete; find $d/$p -name "*agent_info.csv" -delete
     echo "$arg $p done"
   done
 done
