@@ -280,7 +280,8 @@ def main():
                          "launch: one ctypes->hipLaunchKernel per step")
     ap.add_argument("--ring", type=int, default=50, help="distinct action batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-large", action="store_true", help="skip the HBM-sized second roofline point (1 Mi envs)")
+    ap.add_argument("--no-large", action="store_true",
+                    help="skip the extra measurements: the HBM-sized second roofline point (1 Mi envs) and roofline_steady")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -417,7 +418,7 @@ def main():
             "episode_metrics": summ,
             "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + len(devs)),
         }
-        if world == 1 and K < 500:
+        if world == 1 and K < 500 and not args.no_large:
             # A K-step region this short holds one graph replay whose launch latency (~10-15 us) is a visible share of it;
             # the same kernel over a 1000-step region of its own (not part of `value`) for the steady per-launch time
             steady = Stepper(step, ring, device, args.mode)

@@ -45,8 +45,8 @@ def test_single_gpu_line():
 def test_driver_sized_run_is_a_pure_graph_replay():
     """The driver's round-end command (--steps 20 --warmup 5): 20 < ring length, so the region must be ONE replay of a
     20-node graph (round 1 silently ran it as 20 eager launches and reported half the rate the kernel earns)."""
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-                          "--no-large"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 1
