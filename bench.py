@@ -42,11 +42,11 @@ def algorithmic_bytes_per_env_step(n_agents, n_bodies=0):
     return 107 * n_agents + 24 + 32 * n_bodies
 
 
-def measured_traffic(kernel_name, grid_threads):
+def measured_traffic(kernel_name, shape):
     """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json, written by
-    tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs).  A summary is only used when it was
-    taken from THIS build of the kernels (hash of csrc/ + include/) and for this kernel and grid: a stale file
-    yields None rather than a number that no longer describes the code."""
+    tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/profile_round.sh).  A summary is only
+    used when it was taken from THIS build of the kernels (hash of csrc/ + include/) and for this kernel and workload
+    shape ("ExN[+B][f]"): a stale file yields None rather than a number that no longer describes the code."""
     import glob
     from gym_uav_collision_avoidance_amd import _lib
     sha = _lib.source_hash()
@@ -58,7 +58,7 @@ def measured_traffic(kernel_name, grid_threads):
             continue
         for entry in (d.get("kernels") or [d]):
             meta = entry.get("_meta", {})
-            if (meta.get("csrc_sha") == sha and meta.get("grid") == grid_threads
+            if (meta.get("csrc_sha") == sha and meta.get("shape") == shape
                     and str(meta.get("kernel", "")).replace("void ", "").startswith(kernel_name)
                     and "hbm_traffic_bytes_per_launch" in entry):
                 best = (entry["hbm_traffic_bytes_per_launch"]["total"], os.path.basename(f))
@@ -322,12 +322,10 @@ def main():
         ring = polar_actions(gen, (args.ring, E), float(np.sqrt(288.0)), device)  # ||(12,12)||, test_sac.py:77
         step = env.step
         bytes_per_env_step, kernel_name = 93, "uavx::uw_step_kernel"
-        block = 64
     else:
         env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, env_offset=rank * E, seed=0,
                                      **(dict(num_bodies=B) if B else {}))
         bytes_per_env_step = algorithmic_bytes_per_env_step(N, B)
-        block = 64
         if args.fused:
             ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
             step = lambda a: env.step_ex(a, polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
@@ -376,9 +374,8 @@ def main():
         if args.fused:
             summ["ended_episodes"] = env.evaluation_summary()
         slots = N + B
-        epw = min(64 // N, 192 // slots) if B else 64 // N   # envs per wavefront (uavx_create)
-        grid_threads = -(-E // epw) * 64 if args.world == "multi" else -(-E // block) * block
-        traffic = measured_traffic(kernel_name, grid_threads)   # step and step_ex kernels have PMC summaries of their own
+        shape = f"{E}x{N}" + (f"+{B}" if B else "") + ("f" if args.fused else "")   # the tag tools/profile_round.sh files it under
+        traffic = measured_traffic(kernel_name, shape) if args.world == "multi" else None
         ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
         world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
         if args.world == "multi" and E == 65536 and N == 4 and B == 0:
