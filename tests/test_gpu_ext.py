@@ -338,6 +338,41 @@ def test_randomized_extension_shapes(amd, oracle_mod):
         env.close()
 
 
+def test_prefetch_side_kernel_on_a_caller_stream(amd, oracle_mod):
+    """uavx_step_ex queues its layout-prefetch kernel on a side stream of the handle, forked from and joined into the CALLER's
+    stream: drive everything from a non-default torch stream, prefetch on every call, no host synchronisation between the
+    calls of a burst -- results must still be the oracle's (an ordering hole would show as a stale or torn layout)."""
+    import torch
+    E, L, B = 2048, 8, 16
+    kw = dict(num_agents=L, num_bodies=B, body_period=4, x_size=20.0, y_size=20.0, d_sense=8.0, collider_radius=0.5)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=12, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.set_prefetch(1)
+    side = torch.cuda.Stream(env.device)
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(48, E, L, 2)).astype(np.float32)
+    d_acts = torch.from_numpy(acts).to(env.device)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        env.reset()
+        outs = []
+        for t in range(48):     # a burst: nothing but launches on `side`
+            o, r, d, info = env.step_ex(d_acts[t], polar=True, auto_reset="agent0_done", step_cap=5)
+            outs.append((o.clone(), r.clone(), d.clone(), info["reset_mask"].clone(), info["truncated"].clone()))
+        bodies = env.get_bodies()
+    side.synchronize()
+    orc.reset_philox(12)
+    for t in range(48):
+        o_o, r_o, d_o, rm, en, tr = orc.step_ex(acts[t], action_mode=1, reset_policy=1, step_cap=5, seed=12, with_end=True)
+        o, r, d, m, tru = outs[t]
+        np.testing.assert_array_equal(_np(m).astype(np.uint8), rm, err_msg=f"step {t}")
+        np.testing.assert_array_equal(_np(tru).astype(np.uint8), tr, err_msg=f"step {t}")
+        np.testing.assert_array_equal(_np(d).astype(np.uint8), d_o, err_msg=f"step {t}")
+        assert obs_err(_np(o), o_o) <= TOL and float(np.abs(_np(r) - r_o).max()) <= TOL, t
+    np.testing.assert_array_equal(_np(bodies), orc.body)
+    env.close()
+
+
 def test_static_obstacles_single_uav(amd, oracle_mod):
     """BASELINE configs[0] / [1] name "1 UAV + static obstacles": a body with speed 0 is a static obstacle.  One learner among
     12 of them: the records never move, the learner senses / collides with them exactly as the oracle says."""
