@@ -20,6 +20,7 @@ PASS[sq]="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLE
 PASS[sq2]="SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM"
 for arg in "$@"; do
   if [ "$arg" = calib ]; then
+    [ -x tools/micro/fetch_calib ] || hipcc -O3 --offload-arch=gfx950 -o tools/micro/fetch_calib tools/micro/fetch_calib.hip
     d=$OUT/calib; rm -rf $d; mkdir -p $d
     for p in fetch write tcc_ea tcc_hit; do
       rocprofv3 --output-format csv --kernel-trace --pmc ${PASS[$p]} -d $d/$p -o run -- tools/micro/fetch_calib > $d/$p.log 2>&1
