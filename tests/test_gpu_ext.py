@@ -373,6 +373,31 @@ def test_prefetch_side_kernel_on_a_caller_stream(amd, oracle_mod):
     env.close()
 
 
+def test_vector_env_surface_with_bodies(amd, oracle_mod):
+    """The VectorEnv-shaped view over a world with scripted bodies: spaces stay per LEARNER, one fused launch per step,
+    info carries reset_mask / ended / truncated."""
+    import torch
+    E, L, B = 640, 4, 6
+    kw = dict(num_agents=L, num_bodies=B, body_period=8, x_size=22.0, y_size=22.0, d_sense=8.0)
+    venv = amd.UAVVectorEnv(E, auto_reset="agent0_done", step_cap=9, polar=True, seed=4, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    assert venv.observation_space.shape == (E, L, 10) and venv.action_space.shape == (E, L, 2) and venv.num_agents == L
+    obs = venv.reset()
+    orc.reset_philox(4)
+    assert obs_err(_np(obs), orc.observe()) <= TOL
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
+        obs, rew, done, info = venv.step(torch.from_numpy(a).to(venv.device))
+        o_o, r_o, d_o, rm, en, tr = orc.step_ex(a, action_mode=1, reset_policy=1, step_cap=9, track_returns=True, seed=4, with_end=True)
+        np.testing.assert_array_equal(_np(done).astype(np.uint8), d_o)
+        for key, want in (("reset_mask", rm), ("ended", en), ("truncated", tr)):
+            np.testing.assert_array_equal(_np(info[key]).astype(np.uint8), want, err_msg=f"{key} step {t}")
+        assert obs_err(_np(obs), o_o) <= TOL and float(np.abs(_np(rew) - r_o).max()) <= TOL
+    np.testing.assert_array_equal(_np(venv.env.get_bodies()), orc.body)
+    venv.close()
+
+
 def test_static_obstacles_single_uav(amd, oracle_mod):
     """BASELINE configs[0] / [1] name "1 UAV + static obstacles": a body with speed 0 is a static obstacle.  One learner among
     12 of them: the records never move, the learner senses / collides with them exactly as the oracle says."""
