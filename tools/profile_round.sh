@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/prof/<shape>/<pass>/ (run on the GPU box through gpurun), then
 #   python tools/summarize_profiles.py rNN   condenses it into profiles/.
-# usage: tools/profile_round.sh [calib] [ExN[+B][f] ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f
+# usage: tools/profile_round.sh [calib] [ExN[+B][f] | uwE ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f uw1048576
 #        (+B: scripted bodies; trailing f: the fused uavx_step_ex path with polar actions, auto-reset and statistics)
 # Kernel trace and each counter group are separate runs (counter collection serialises and slows kernels); the
 # program itself follows `--` (no env / bash -c hop).  TCC has 4 counter slots per pass, SQ 8.
@@ -28,11 +28,15 @@ for arg in "$@"; do
     done
     continue
   fi
-  fused=""; a=$arg; [[ "$a" == *f ]] && { fused="--fused"; a=${a%f}; }
-  shape=${a%%+*}; bodies=0; [[ "$a" == *+* ]] && bodies=${a##*+}
-  E=${shape%%x*}; N=${shape##*x}
   d=$OUT/$arg; rm -rf $d; mkdir -p $d
-  BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large $fused"
+  if [[ "$arg" == uw* ]]; then   # uwE: the UAVWorld2D kernel on E envs
+    BARGS="--world uw --envs ${arg#uw} --ring 8 --no-cpu-baseline --no-large"
+  else
+    fused=""; a=$arg; [[ "$a" == *f ]] && { fused="--fused"; a=${a%f}; }
+    shape=${a%%+*}; bodies=0; [[ "$a" == *+* ]] && bodies=${a##*+}
+    E=${shape%%x*}; N=${shape##*x}
+    BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large $fused"
+  fi
   rocprofv3 --output-format csv --kernel-trace --stats -d $d/kt -o run -- python3 bench.py $BARGS --steps 1000 --warmup 100 > $d/kt.log 2>&1
   find $d/kt -name "*kernel_trace.csv" -delete; find $d/kt -name "*agent_info.csv" -delete   # keep the stats summary only (64 MiB merge limit)
   echo "$arg kt done"
