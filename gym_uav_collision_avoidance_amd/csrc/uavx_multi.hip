@@ -141,6 +141,7 @@ struct LaneMap {
     int lane;        // thread in its workgroup (the lane when the workgroup is one wavefront)
     int i, base;     // agent index in its env, first lane of the env's group
     int rbase, nslots;  // first LDS neighbour row of the env, rows per env (N unless the env has scripted bodies)
+    int nlearn;         // the first nlearn rows of an env are agents with a lane each (= N)
     int g;              // env index within the workgroup
     bool active;
     uint32_t e, a;   // env, agent slot (E*N < 2^26, checked by uavx_create)
@@ -176,6 +177,7 @@ __device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
     m.base = m.active ? (g * N) & (kWave - 1) : 0;  // first lane of the env's group in its wavefront (W == 1: ballot shifts)
     m.g = m.active ? g : 0;
     m.nslots = EXT ? p.nslots : N;
+    m.nlearn = N;
     m.rbase = m.active ? g * m.nslots : 0;  // idle lanes still execute the LDS scan: keep it in bounds
     m.a0 = e0 * N;
     m.a = m.a0 + m.lane;            // whole envs are packed from thread 0: slot = a0 + thread
@@ -337,11 +339,11 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const WorldLims &w, const
 }
 
 // Same result for N > 5 (and the N = 8 specialisation) at about half the per-neighbour cost: the scan keeps the
-// three smallest KEYS, key = (bits of the squared distance with the low 6 bits replaced by the agent index), with
+// three smallest KEYS, key = (bits of the squared distance with the low 6 bits replaced by a name of the neighbour), with
 // one v_min_u32 + two v_med3_u32 per neighbour instead of a compare/select insertion of (distance, index)
 // pairs, and takes square roots only of the two winners (their exact squared distances are recomputed from LDS).
 // Non-negative floats order like their bit patterns and NaN / +inf patterns sort above every finite value, so
-// keys order by (squared distance truncated to 2^-17 relative, index).  sqrtf is monotone and two squared
+// keys order by (squared distance truncated to 2^-17 relative, name).  sqrtf is monotone and two squared
 // distances whose truncations differ by two or more steps have different float32 roots, so the order by key
 // equals the reference's order by (float32 distance, index) (AG:52-62) unless two of the kept keys are within
 // one truncation step of each other at or below the sensing limit -- then (about 1 wave in 1000 on random
@@ -365,7 +367,14 @@ __device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneM
     const float4 *row = &lds.pos[m.rbase];
     uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
     float step_min = INFINITY;
-    auto visit = [&](int j, bool below, float4 q) {   // below: j < m.i
+    // The low 6 bits of a key only have to NAME the neighbour (two keys that agree above them are a near tie and take the
+    // exact scan): they hold c = the neighbour's rank among the OTHER slots of the env (slot j = c + (c >= i)), which is
+    // the same number in every lane -- the row address is then the lane's base + 16 c (+ 16 from agent i upwards) and the
+    // key needs no per-lane index register.
+    // (the mask sits in a VGPR so that the wave-uniform name can be the one scalar operand of a single v_and_or_b32)
+    uint32_t keep;
+    asm("v_mov_b32 %0, 0xffffffc0" : "=v"(keep));
+    auto visit = [&](uint32_t c, bool below, float4 q) {   // below: slot < m.i (already moved in this step)
         const float dxn = q.z - nx, dyn = q.w - ny;
         const float ax = dxn * dxn, ay = dyn * dyn;
         const float sn = ax + ay;
@@ -375,45 +384,52 @@ __device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneM
             const float so = bx + by;
             step_min = fminf(step_min, below ? sn : so);  // fminf drops NaN; the d_sense test follows the loop
         }
-        const uint32_t key = (__float_as_uint(sn) & ~63u) | (uint32_t)j;
+        uint32_t key;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(sn), "v"(keep), "s"(c));
         k3 = med3_u32(k2, k3, key);
         k2 = med3_u32(k1, k2, key);
         k1 = min(k1, key);
     };
+    const char *rowb = reinterpret_cast<const char *>(row);
+    auto other = [&](int c, bool below) {   // the c-th other slot of the env as seen from agent i
+        return *reinterpret_cast<const float4 *>(rowb + c * 16 + (below ? 0 : 16));
+    };
     if (NT) {  // compile-time N: all LDS reads issued before the first use
         constexpr int M = NT > 1 ? NT - 1 : 1;
         float4 q[M];
-        int js[M];
 #pragma unroll
-        for (int k = 0; k < NT - 1; k++) {
-            js[k] = k + (k >= m.i ? 1 : 0);  // ascending over the other agents, self skipped
-            q[k] = row[js[k]];
-        }
+        for (int c = 0; c < NT - 1; c++) q[c] = other(c, c < m.i);
 #pragma unroll
-        for (int k = 0; k < NT - 1; k++) visit(js[k], js[k] < m.i, q[k]);
+        for (int c = 0; c < NT - 1; c++) visit((uint32_t)c, c < m.i, q[c]);
     } else {
-        // two neighbours per trip, written out (inline asm is convergent in HIP, which rules out the unroll pragma);
-        // the k-th other agent is j = k (below me: already moved) or k + 1 (above me: not yet) -- ONE compare gives both
-        // the index and the Gauss-Seidel select
-        int k = 0;
-        for (; k + 1 < N - 1; k += 2) {
-            const bool la = k < m.i, lb = k + 1 < m.i;
-            const int ja = la ? k : k + 1, jb = lb ? k + 1 : k + 2;
-            const float4 qa = row[ja], qb = row[jb];
-            visit(ja, la, qa);
-            visit(jb, lb, qb);
+        // two neighbours per trip, written out (inline asm is convergent in HIP, which rules out the unroll pragma)
+        const int NL = m.nlearn;   // slots [0, NL) are agents with a lane each; [NL, N) scripted bodies (extension)
+        int c = 0;
+        for (; c + 1 < NL - 1; c += 2) {
+            const bool la = c < m.i, lb = c + 1 < m.i;
+            const float4 qa = other(c, la), qb = other(c + 1, lb);
+            visit((uint32_t)c, la, qa);
+            visit((uint32_t)c + 1u, lb, qb);
         }
-        if (k < N - 1) {
-            const bool la = k < m.i;
-            const int j = la ? k : k + 1;
-            visit(j, la, row[j]);
+        if (c < NL - 1) {
+            const bool la = c < m.i;
+            visit((uint32_t)c, la, other(c, la));
+            c++;
         }
+        // bodies sit above every learner and move after them (never "already moved"): the Gauss-Seidel select folds away
+        for (; c + 1 < N - 1; c += 2) {
+            const float4 qa = row[c + 1], qb = row[c + 2];
+            visit((uint32_t)c, false, qa);
+            visit((uint32_t)c + 1u, false, qb);
+        }
+        if (c < N - 1) visit((uint32_t)c, false, row[c + 1]);
     }
-    // N > 5: at least five neighbours were visited, so k1..k3 are real keys (their low bits are agent indices)
+    // N > 5: at least five neighbours were visited, so k1..k3 are real keys
     const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(w.sq_sense) >> 6;
     const bool near_tie = (t2 - t1 <= 1u && t1 <= ts) || (t3 - t2 <= 1u && t2 <= ts);
     if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);
-    const int j1 = (int)(k1 & 63u), j2 = (int)(k2 & 63u);
+    const int c1 = (int)(k1 & 63u), c2 = (int)(k2 & 63u);
+    const int j1 = c1 + (c1 >= m.i ? 1 : 0), j2 = c2 + (c2 >= m.i ? 1 : 0);
     const float4 q1 = row[j1], q2 = row[j2];
     const float ex1 = q1.z - nx, ey1 = q1.w - ny, ex2 = q2.z - nx, ey2 = q2.w - ny;
     const float mx1 = ex1 * ex1, my1 = ey1 * ey1, mx2 = ex2 * ex2, my2 = ey2 * ey2;
@@ -479,11 +495,23 @@ __device__ __forceinline__ void store_obs_block(const MultiParams &p, const Lane
             if (f < nfloat) store16_wt(r, gbase + f * 4u, *reinterpret_cast<const float4 *>(stage + f));
         }
     } else {
+        // odd N: the block starts 8 bytes off a 16-byte boundary in every second workgroup and ends likewise.  16-byte
+        // stores for the aligned middle, one 8-byte store for a misaligned head / tail (8-byte write-through stores run at
+        // 0.54-0.70x the 16-byte rate: round 1 wrote the whole block that way)
+        const int head = (gbase & 8u) ? 2 : 0;          // uniform over the workgroup
+        const int mid = (nfloat - head) / 4;              // float4 count
+        const int tail = head + mid * 4;                  // first float after the middle (nfloat - tail is 0 or 2)
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int f = (k * T + m.lane) * 2;
-            if (f < nfloat) store8_wt(r, gbase + f * 4u, *reinterpret_cast<const float2 *>(stage + f));
+        for (int k = 0; k < 3; k++) {
+            const int q = k * T + m.lane;
+            if (q < mid) {
+                const float *src = stage + head + q * 4;   // only 8-byte aligned in LDS: two ds_read_b64
+                const float2 lo = *reinterpret_cast<const float2 *>(src), hi = *reinterpret_cast<const float2 *>(src + 2);
+                store16_wt(r, gbase + (uint32_t)(head + q * 4) * 4u, make_float4(lo.x, lo.y, hi.x, hi.y));
+            }
         }
+        if (m.lane == 0 && head) store8_wt(r, gbase, *reinterpret_cast<const float2 *>(stage));
+        if (m.lane == 1 && tail < nfloat) store8_wt(r, gbase + (uint32_t)tail * 4u, *reinterpret_cast<const float2 *>(stage + tail));
     }
     group_sync<LDS::kW>();
 }
@@ -500,15 +528,19 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
     const bool leveled = p.n_levels > 0;
     const LevelParams *lv = &p.levels[(flags & kLevelMask) >> kLevelShift];   // read only when a curriculum is installed
     const int b_active = m.active ? (leveled ? lv->b_active : p.B) : 0;
-#pragma unroll 1
-    for (int k = 0; k < p.kb; k++) {
+    auto fetch = [&](int k) {
+        const int b = k * L + m.i;
+        const bool on = m.active && b < p.B && b < b_active;
+        float4 r = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+        if (on) r = from_lds ? lds.pos[m.rbase + L + b] : p.body[m.e * (uint32_t)p.B + (uint32_t)b];
+        return r;
+    };
+    auto work = [&](int k, float4 r) {
         const int b = k * L + m.i;
         const bool valid = m.active && b < p.B;
         const bool on = valid && b < b_active;
         const int row = m.rbase + L + (valid ? b : 0);
         const uint32_t gi = m.e * (uint32_t)p.B + (uint32_t)b;
-        float4 r = make_float4(INFINITY, INFINITY, 0.f, 0.f);
-        if (on) r = from_lds ? lds.pos[row] : p.body[gi];
         const float ox = r.x, oy = r.y;
         if (MOVE && on && !frozen) {
             if (steps != 0u && (steps & (uint32_t)p.body_pmask) == 0u) {  // a new waypoint every `period` steps
@@ -533,7 +565,9 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
             lds.theta[row] = atan2_fast(r.w - r.y, r.z - r.x);   // heading: towards the waypoint
         }
         if (MOVE && on && !frozen) p.body[gi] = r;
-    }
+    };
+#pragma unroll 1
+    for (int k = 0; k < p.kb; k++) work(k, fetch(k));
 }
 
 // One env step for this lane's agent (state in registers).  MUW:177-241.
@@ -646,12 +680,16 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 8 : 1) void step_kerne
     uint4 rec = make_uint4(0, 0, 0, 0);
     uint32_t wave_count = 0;
     if (EXT) {  // the bodies' waypoint schedule runs on the env's step count and episode index
-        if (m.active) rec = p.env_rec[m.e];
+        // (unconditional, index clamped for idle lanes: loaded under the `active` branch, the arithmetic on the record was
+        // pulled into that branch together with a full wait -- a memory round trip BEFORE the state loads went out)
+        rec = p.env_rec[m.active ? m.e : 0u];
         wave_count = p.wave_steps[blockIdx.x];
     }
     if (m.active) {
-        load_agent(p, m.a, s);
+        // the command is requested BEFORE the state: load_agent ends in arithmetic on what it loaded (prev_distance), and a
+        // load placed behind that would start a second memory round trip after the first one has come back
         load_action<ACT64>(actions, m.a, ax, ay);
+        load_agent(p, m.a, s);
     }
     const uint32_t flags_in = s.flags;
     float o[10], rew;
@@ -941,8 +979,10 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 7 : 1) void step_ex_ke
     const uint32_t wave_count = p.wave_steps[blockIdx.x];
     __builtin_amdgcn_sched_barrier(0);
     if (m.active) {
-        load_agent(p, m.a, s);
+        // the command is requested BEFORE the state: load_agent ends in arithmetic on what it loaded (prev_distance), and a
+        // load placed behind that would start a second memory round trip after the first one has come back
         load_action<ACT64>(actions, m.a, ax, ay);
+        load_agent(p, m.a, s);
     }
     __builtin_amdgcn_sched_barrier(0);
     const bool do_reset = (rec.y & kRecEnded) != 0;

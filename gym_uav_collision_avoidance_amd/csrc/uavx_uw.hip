@@ -138,10 +138,10 @@ __global__ __launch_bounds__(kBlock) void uw_step_kernel(UwParams p, const void 
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= p.E) return;
     UwRegs s;
+    double ax, ay;
+    uw_load_action<ACT64>(actions, e, ax, ay);   // requested before the state: uw_load ends in arithmetic on what it loaded
     uw_load(p, e, s);
     const uint32_t flags_in = s.flags;
-    double ax, ay;
-    uw_load_action<ACT64>(actions, e, ax, ay);
     float4 obs; float rew, dist; uint32_t dn;
     uw_step_env(p, s, ax, ay, !ACT64, obs, rew, dn, dist);
     obs_out[e] = obs;
@@ -209,10 +209,10 @@ __global__ __launch_bounds__(kBlock) void uw_step_ex_kernel(UwParams p, UwExtra 
             if (x.ended) x.ended[e] = 0;
             if (x.truncated) x.truncated[e] = 0;
         } else {
-            uw_load(p, e, s);
-            const uint32_t flags_in = s.flags;
             double ax, ay;
             uw_load_action<ACT64>(actions, e, ax, ay);
+            uw_load(p, e, s);
+            const uint32_t flags_in = s.flags;
             bool act_f32 = !ACT64;
             if (x.action_mode == UAVX_ACTION_POLAR) {  // test_sac.py:77-80 in float32
                 const float v = fmaf((float)ax, 0.5f, 0.5f) * p.high0;
