@@ -275,6 +275,14 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="multi only: drive uavx_step_ex (polar action conversion, agent0-done auto-reset with a "
                          "1500-step cap, episode statistics) instead of the bare step")
+    ap.add_argument("--curriculum", type=int, default=0, metavar="LEVELS",
+                    help="multi only: install this many curriculum levels (box 30..60 m, d_sense 10..18 m, fewer active learners / "
+                         "bodies on the lower ones); every (re-)initialised env draws its level uniformly over all of them")
+    ap.add_argument("--replay", action="store_true",
+                    help="with --fused: obs / reward / done / episode flags land zero-copy in a DeviceReplay ring of --ring slots "
+                         "and the commands are read from its action slots")
+    ap.add_argument("--cfg5", action="store_true",
+                    help="BASELINE configs[4] as designed: --agents 8 --bodies 16 --fused --curriculum 4 --replay")
     ap.add_argument("--mode", choices=("graph", "launch"), default="graph",
                     help="graph: steps replayed from captured hipGraphs (one kernel node per step); "
                          "launch: one ctypes->hipLaunchKernel per step")
@@ -283,6 +291,13 @@ def main():
     ap.add_argument("--no-large", action="store_true",
                     help="skip the extra measurements: the HBM-sized second roofline point (1 Mi envs) and roofline_steady")
     args = ap.parse_args()
+    if args.cfg5:
+        args.agents, args.bodies, args.fused, args.replay = 8, 16, True, True
+        args.curriculum = args.curriculum or 4
+    if args.replay and not args.fused:
+        raise SystemExit("--replay needs --fused (the replay ring is fed by uavx_step_ex)")
+    if args.world == "uw" and (args.curriculum or args.replay or args.bodies):
+        raise SystemExit("--curriculum / --replay / --bodies belong to --world multi")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -311,11 +326,13 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D, BatchedUAVWorld2D
+    from gym_uav_collision_avoidance_amd.replay import DeviceReplay
     from gym_uav_collision_avoidance_amd.sharding import gather_episode_metrics, summarize_metrics
 
     E, N, B, K, W = args.envs, args.agents, args.bodies, args.steps, args.warmup
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     nt = lambda n: n if n in (1, 2, 4, 8) else 0
+    ext = False
     if args.world == "uw":
         N, B = 1, 0
         env = BatchedUAVWorld2D(E, device=device, env_offset=rank * E, seed=0)
@@ -326,15 +343,32 @@ def main():
         env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, env_offset=rank * E, seed=0,
                                      **(dict(num_bodies=B) if B else {}))
         bytes_per_env_step = algorithmic_bytes_per_env_step(N, B)
+        ext = bool(B or args.curriculum)    # the kernel variant with bodies / levels (runtime agent count)
+        if args.curriculum:
+            n = args.curriculum
+            f = lambda a, b, k: a + (b - a) * k / max(1, n - 1)
+            env.set_curriculum([dict(x_size=f(30.0, 60.0, k), y_size=f(30.0, 60.0, k), collider_radius=1.0, d_sense=f(10.0, 18.0, k),
+                                     n_active=max(1, round(f(N / 2, N, k))), b_active=round(f(B / 4, B, k))) for k in range(n)],
+                               lo=0, hi=n - 1)
         if args.fused:
             ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
-            step = lambda a: env.step_ex(a, polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
-            kernel_name = f"uavx::step_ex_kernel<{0 if B else nt(N)}"
+            fused_kw = dict(polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
+            if args.replay:
+                # slot k of the ring holds the command, reward, done and flags of step k and the observation step k - 1
+                # produced: the launch reads replay.act[k] and writes obs -> slot k + 1, the rest -> slot k (nothing is copied)
+                replay = DeviceReplay(env, horizon=args.ring - 1, num_learners=N)
+                replay.act.copy_(ring)
+                step = lambda a: replay.step(None, **fused_kw)
+            else:
+                step = lambda a: env.step_ex(a, **fused_kw)
+            kernel_name = f"uavx::step_ex_kernel<{0 if ext else nt(N)}"
         else:
             ring = polar_actions(gen, (args.ring, E, N), float(np.sqrt(200.0)), device)
             step = env.step
-            kernel_name = f"uavx::step_kernel<{0 if B else nt(N)}"
-    env.reset()
+            kernel_name = f"uavx::step_kernel<{0 if ext else nt(N)}"
+    obs0 = env.reset()
+    if args.world == "multi" and args.replay:
+        replay.begin(obs0)
 
     stepper = Stepper(step, ring, device, args.mode)
     stepper.prepare(K)
@@ -374,9 +408,12 @@ def main():
         if args.fused:
             summ["ended_episodes"] = env.evaluation_summary()
         slots = N + B
-        shape = f"{E}x{N}" + (f"+{B}" if B else "") + ("f" if args.fused else "")   # the tag tools/profile_round.sh files it under
+        shape = (f"{E}x{N}" + (f"+{B}" if B else "") + ("f" if args.fused else "")   # the tag tools/profile_round.sh files it under
+                 + (f"c{args.curriculum}" if args.curriculum else "") + ("r" if args.replay else ""))
         traffic = measured_traffic(kernel_name, shape) if args.world == "multi" else None
         ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
+        if args.replay:   # every slot of the ring has its own obs / reward / done / flag rows
+            ws += E * (args.ring - 1) * (N * 45 + 3)
         world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
         if args.world == "multi" and E == 65536 and N == 4 and B == 0:
             cfg_tag = "BASELINE.json configs[2]"
@@ -399,14 +436,16 @@ def main():
             "data": "synthetic", "repeats": len(walls), "repeat_ms_per_step": [w * 1e3 / K for w in walls],
             "config": {"workload": f"{E} envs x {N} UAVs" + (f" + {B} scripted bodies" if B else "") + f" per GPU ({cfg_tag}), "
                                    f"{world_name} defaults, polar U(-1,1)^2 actions from a {args.ring}-batch HBM ring, mode={mode}"
-                                   + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else ""),
-                       "envs_per_gpu": E, "agents": N, "bodies": B, "parallelism": f"env-index shard x{world}", "mode": mode,
+                                   + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else "")
+                                   + (f", randomized-reset curriculum over {args.curriculum} levels" if args.curriculum else "")
+                                   + (f", outputs written zero-copy into a {args.ring}-slot on-device replay ring" if args.replay else ""),
+                       "envs_per_gpu": E, "agents": N, "bodies": B, "curriculum_levels": args.curriculum, "replay": bool(args.replay), "parallelism": f"env-index shard x{world}", "mode": mode,
                        "graph_replays": replays},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
-                         "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else (",false,true>" if B else ",false,false>")),
+                         "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else (",false,true>" if ext else ",false,false>")),
                          "note": note},
             "gather_ms": gather_s * 1e3,
             "gather_note": "counter read + one gather of [E,4] episode metrics to rank 0 (once per episode, not per step); "

@@ -1380,6 +1380,8 @@ struct uavx_handle {
     // pre-drawn layouts: prefetch_kernel runs on `side` next to every prefetch_every-th auto-resetting uavx_step_ex launch
     int prefetch_every = 16;   // 0: off
     uint64_t ex_calls = 0;
+    bool in_capture = false;           // the previous auto-resetting call was recorded into stream capture `capture_id`
+    unsigned long long capture_id = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ext = false;
@@ -2016,6 +2018,19 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     // work already queued on `stream`, joined back before this call returns control of `stream`; capturable)
     const bool resets = a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0;
     x.use_stage = (h->prefetch_every > 0 && resets) ? 1 : 0;
+    if (x.use_stage) {
+        // A call recorded into a stream capture runs once per REPLAY of the graph: the first recorded call of every capture
+        // carries the side launch (and the count restarts there), so a graph of fewer than `every` steps still draws
+        // ahead once per replay instead of never / always depending on where the call count happened to stand.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        unsigned long long cid = 0;
+        if (hipStreamGetCaptureInfo(st, &cs, &cid) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusActive) {
+            if (!h->in_capture || cid != h->capture_id) { h->in_capture = true; h->capture_id = cid; h->ex_calls = 0; }
+        } else {
+            h->in_capture = false;
+        }
+    }
     const bool stage = x.use_stage && (h->ex_calls++ % (uint64_t)h->prefetch_every) == 0;
     if (stage) {
         UAVX_HIP(h, hipEventRecord(h->ev_fork, st));

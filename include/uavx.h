@@ -248,7 +248,9 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
  * start next; a step launch then re-initialises an env with 16-byte copies instead of running the serial accept / reject
  * chain of MUW:127-153 on one wavefront while the rest of the chip waits for it (profiles/r02_ab_notes.md).  A layout parked
  * for another seed / world / level, or an episode that ends before the next side launch, simply misses and is drawn in the
- * step launch as before: results are identical either way.  every = 0 switches the side kernel off. */
+ * step launch as before: results are identical either way.  every = 0 switches the side kernel off.
+ * Calls recorded into a stream capture: the first recorded call of each capture carries the side launch and the count restarts
+ * there, so every replay of a graph of n steps draws ahead ceil(n / every) times wherever the call count stood before. */
 int uavx_set_prefetch(uavx_handle *h, int every);
 
 /* Per-env statistics over the episodes ended so far (by auto-reset or uavx_reset):

@@ -56,6 +56,20 @@ def test_driver_sized_run_is_a_pure_graph_replay():
     assert st["steps"] == 1000 and st["frac"] >= d["roofline"]["frac"] and st["kernel_us"] > 3.0
 
 
+def test_cfg5_as_designed_line():
+    """BASELINE configs[4] in one launch sequence: 8 learners + 16 scripted bodies, fused step_ex with auto-reset, a
+    randomized-reset curriculum and the outputs landing in the on-device replay ring (small batch: the line, not the rate)."""
+    out = subprocess.run([sys.executable, "bench.py", "--cfg5", "--envs", "2048", "--ring", "8", "--steps", "64", "--warmup", "8",
+                          "--repeats", "2", "--no-cpu-baseline", "--no-large"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    c = d["config"]
+    assert c["agents"] == 8 and c["bodies"] == 16 and c["curriculum_levels"] == 4 and c["replay"] is True
+    assert c["mode"] == "graph" and c["graph_replays"] == 8 and "replay ring" in c["workload"]
+    assert d["roofline"]["kernel"].startswith("uavx::step_ex_kernel<0") and d["value"] > 1e6
+    assert d["episode_metrics"]["ended_episodes"]["episodes"] >= 0
+
+
 def test_two_rank_rehearsal():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, UAVX_REHEARSAL="1")

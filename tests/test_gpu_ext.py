@@ -373,6 +373,64 @@ def test_prefetch_side_kernel_on_a_caller_stream(amd, oracle_mod):
     env.close()
 
 
+def test_step_ex_replayed_from_a_short_hipgraph(amd, oracle_mod):
+    """A 6-step hipGraph of fused step_ex launches (shorter than the default 16-call prefetch cadence), replayed 8 times with
+    fresh commands: the first recorded call of the capture carries the layout-prefetch side launch, so every replay draws
+    ahead once -- and whatever is parked or missed, the results are the oracle's."""
+    import torch
+    E, L, B, G, R = 1024, 8, 16, 6, 8
+    kw = dict(num_agents=L, num_bodies=B, body_period=4, x_size=20.0, y_size=20.0, d_sense=8.0, collider_radius=0.5)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=21, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(-1, 1, size=(R, G, E, L, 2)).astype(np.float32)
+    tape = torch.from_numpy(acts).to(env.device)
+    slot = torch.zeros((G, E, L, 2), dtype=torch.float32, device=env.device)
+    obs = torch.zeros((G, E, L, 10), dtype=torch.float32, device=env.device)
+    rew = torch.zeros((G, E, L), dtype=torch.float32, device=env.device)
+    done = torch.zeros((G, E, L), dtype=torch.uint8, device=env.device)
+    flags = torch.zeros((G, 3, E), dtype=torch.uint8, device=env.device)
+    step = lambda i: env.step_ex(slot[i], polar=True, auto_reset="agent0_done", step_cap=7, out=(obs[i], rew[i], done[i]),
+                                 flags_out=(flags[i, 0], flags[i, 1], flags[i, 2]))
+    env.reset()
+    side = torch.cuda.Stream(env.device)
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(side):          # lazy initialisation outside the capture; these three steps count as steps
+        slot.copy_(tape[0])
+        for i in range(3):
+            step(i)
+        warm = [t.clone() for t in (obs[:3], rew[:3], done[:3], flags[:3])]
+    torch.cuda.current_stream(env.device).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(G):
+            step(i)
+    got = []
+    for r in range(R):
+        slot.copy_(tape[r])
+        g.replay()
+        got.append([t.clone() for t in (obs, rew, done, flags)])
+    bodies = env.get_bodies()
+    torch.cuda.synchronize()
+    orc.reset_philox(21)
+
+    def check(a, o, r, d, f, tag):
+        o_o, r_o, d_o, rm, en, tr = orc.step_ex(a, action_mode=1, reset_policy=1, step_cap=7, seed=21, with_end=True)
+        np.testing.assert_array_equal(_np(f[0]), rm, err_msg=tag)
+        np.testing.assert_array_equal(_np(f[1]), en, err_msg=tag)
+        np.testing.assert_array_equal(_np(f[2]), tr, err_msg=tag)
+        np.testing.assert_array_equal(_np(d), d_o, err_msg=tag)
+        assert obs_err(_np(o), o_o) <= TOL and float(np.abs(_np(r) - r_o).max()) <= TOL, tag
+    for i in range(3):
+        check(acts[0, i], warm[0][i], warm[1][i], warm[2][i], warm[3][i], f"warm-up step {i}")
+    for r in range(R):
+        o, w, d, f = got[r]
+        for i in range(G):
+            check(acts[r, i], o[i], w[i], d[i], f[i], f"replay {r} step {i}")
+    np.testing.assert_array_equal(_np(bodies), orc.body)
+    env.close()
+
+
 def test_vector_env_surface_with_bodies(amd, oracle_mod):
     """The VectorEnv-shaped view over a world with scripted bodies: spaces stay per LEARNER, one fused launch per step,
     info carries reset_mask / ended / truncated."""
