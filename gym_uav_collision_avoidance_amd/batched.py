@@ -214,8 +214,9 @@ class BatchedMultiUAVWorld2D(_Base):
         return t
 
     def set_prefetch(self, every=16):
-        """Pre-drawn reset layouts (uavx_set_prefetch): the layouts of the episodes that start next are drawn by a side
-        kernel on every `every`-th step_ex call; 0 / False = off (every auto-reset draws inside the step launch)."""
+        """Reset layouts drawn ahead of time (uavx_set_prefetch): every auto-resetting step_ex launch carries staging
+        workgroups that draw the next episodes' layouts for 1/`every` of the envs (rotating); 0 / False = off (every
+        auto-reset draws in place, inside its step workgroup).  Results do not depend on it."""
         _lib.check(self._L.uavx_set_prefetch(self._h, int(every)), self._h)
 
     def get_bodies(self):

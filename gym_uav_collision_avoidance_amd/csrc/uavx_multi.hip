@@ -109,10 +109,10 @@ struct MultiParams {
     float4 *body;                 // [E*B] {x, y, wx, wy}
     uint8_t *lvl_cur, *lvl_next;  // [E] level in force / level assigned for the next reset
     const LevelParams *levels;    // [UAVX_MAX_LEVELS] device table, read only while a curriculum is installed (n_levels > 0)
-    // ---- pre-drawn layouts (uavx_step_ex auto-reset; see prefetch_kernel) ----
+    // ---- pre-drawn layouts (uavx_step_ex auto-reset; see stage_ahead) ----
     // The layout of an env's NEXT episode is a pure function of (seed, global env, episode index, level rule), so it is
-    // drawn ahead of time by a kernel that runs BESIDE the step launch and parked here; the step launch that re-initialises
-    // the env then copies 16 B per slot instead of running the serial accept / reject chain on one wavefront while the
+    // drawn ahead of time by staging workgroups at the front of an earlier step launch and parked here; the step launch that
+    // re-initialises the env then copies 16 B per slot instead of running the serial accept / reject chain on one wavefront while the
     // rest of the chip waits for it.  stage_tag says exactly what a parked layout was drawn for; anything else is a miss
     // and falls back to drawing in the step launch.
     float4 *stage_agent;          // [E*L] {sx, sy, tx, ty}
@@ -134,7 +134,10 @@ struct StepExtra {
     uint32_t seed_lo, seed_hi;
     uint8_t *reset_mask;
     uint8_t *ended, *truncated;
-    int use_stage;   // consult the pre-drawn layouts (prefetch_kernel runs beside this launch)
+    int use_stage;   // consult the pre-drawn layouts
+    // layouts drawn ahead: the first pf_blocks workgroups of the launch do not step anything -- they draw the layouts of the
+    // NEXT episodes of one slice of the envs (see stage_ahead); env-workgroup w is workgroup pf_blocks + w
+    uint32_t pf_blocks, pf_groups;   // leading workgroups, env-workgroups of the launch
 };
 
 struct LaneMap {
@@ -154,12 +157,11 @@ struct LaneMap {
 // packed from thread 0 (so agent slot = a0 + thread id).  W = 1 everywhere except for agent counts that would leave
 // many lanes of a single wavefront idle (N = 24: 48 of 64; three wavefronts hold 8 envs with none idle).
 template <int NT, bool EXT = false, int W = 1>
-__device__ __forceinline__ LaneMap lane_map(const MultiParams &p) {
+__device__ __forceinline__ LaneMap lane_map(const MultiParams &p, uint32_t wave = blockIdx.x) {   // wave: env-workgroup index
     LaneMap m;
     const int N = NT ? NT : p.N;
     const int epw = NT ? (kWave / (NT ? NT : 1)) : p.epw;
     m.lane = threadIdx.x;            // thread in its workgroup (= lane for W == 1)
-    const uint32_t wave = blockIdx.x;   // workgroup index (= wavefront index for W == 1)
     int g;
     if (NT) {
         g = m.lane / (NT ? NT : 1);
@@ -951,19 +953,68 @@ __device__ unsigned int g_stamp_n;
 #define STAMP(k)
 #endif
 
+// Layouts drawn ahead of time, inside the step launch.  The layout of an env's NEXT episode is a pure function of (seed,
+// global env, episode index, level rule); re-initialising an env from a parked layout costs 16-byte copies, drawing it in
+// place costs a serial accept / reject chain on ONE wavefront (a few thousand instructions with scripted bodies) that the
+// whole launch then waits for.  So the first pf_blocks workgroups of every auto-resetting uavx_step_ex launch draw instead of
+// stepping: launch c looks after slice c mod S of the env-workgroups (S = ceil(G / pf_blocks), c = the handle's step count
+// in device memory, so replays of a captured graph rotate like eager calls do), finds the envs whose parked layout is missing
+// or was drawn for something else, and runs their chains -- started first, they finish underneath the step workgroups of
+// the same launch.  An env is looked after once every S launches; one that ends two episodes within S launches misses and
+// draws in its step workgroup as before (same result either way).
+// Safe against the step workgroups of the same launch: those only READ the staging arrays of an env they re-initialise,
+// and publish the env's new episode index (env_rec.y) after those reads have returned -- a staging workgroup either sees
+// the old index (and finds the parked layout still right: nothing to do) or the new one (and may overwrite a layout that
+// has been consumed).
+template <int NT, bool EXT, int W, class LDS>
+__device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtra &x, LDS &lds) {
+    // the launch counter: env-workgroup 0's step count, which its step workgroup moves on at the END of every launch.  (A
+    // staging workgroup that read it only after that -- dispatched 20 us late -- would look after the next slice instead:
+    // harmless, every slice is as good as any other.  A shared arrival counter would make the rotation exact, but 512
+    // same-address atomics per launch serialise at ~25 ns each.)
+    const uint32_t c = p.wave_steps[0];
+    const uint32_t slices = (x.pf_groups + x.pf_blocks - 1u) / x.pf_blocks;
+    const uint32_t w = (c % slices) * x.pf_blocks + blockIdx.x;
+    if (w >= x.pf_groups) return;
+    const LaneMap m = lane_map<NT, EXT, W>(p, w);
+    uint32_t episode = 0;
+    bool need = false;
+    if (m.active) {
+        episode = p.env_rec[m.e].y & ~kRecEnded;   // the index the env's next reset draws with
+        need = !stage_hit(p.stage_tag[m.e], stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
+    }
+    if (!group_any<W>(need)) return;
+    __builtin_amdgcn_s_setprio(3);   // a serial chain the launch must not end up waiting for: issue ahead of the SIMD mates
+    AgentRegs s = {};
+    reset_envs_wave<NT, EXT>(p, m, lds, need, episode, x.seed_lo, x.seed_hi, s, p.stage_body, nullptr);
+    if (need) {
+        p.stage_agent[m.a] = make_float4(s.x, s.y, s.tx, s.ty);
+        if (m.i == 0) {
+            uint4 tag = stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi);
+            tag.w = (tag.w & ~0xFFu) | (EXT ? ((s.flags & kLevelMask) >> kLevelShift) : 0u);   // the level it drew
+            p.stage_tag[m.e] = tag;
+        }
+    }
+}
+
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
 // episode returns, next-step auto-reset).  Same step_agent body as step_kernel.
 // Register budget (profiles/r02_ab_notes.md): one agent record instead of three and the statistics fold read back at the end
-// took the variant with bodies from 83 to 72 VGPRs and the N = 8 one from 89 to 79; with bodies a bound of 7 wavefronts
-// per SIMD is kept (the same bound on the N = 8 variant spills in its hot path: 11.3 -> 16.1 us, not applied).
+// took the variant with bodies from 83 to 72 VGPRs and the N = 8 one from 89 to 79; with the staging path (stage_ahead) in the
+// same kernel the variant with bodies is bounded at 6 wavefronts per SIMD (74 VGPRs, no spill; 7 = 72 VGPRs with scratch
+// reloads in the hot path: 22.3 -> 23.8 us).  The same kind of bound on the N = 8 variant spills in its hot path, not applied.
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 7 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 6 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                             int evaluate, float *__restrict__ obs_out,
                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
     const int N = NT ? NT : p.N;
-    const LaneMap m = lane_map<NT, EXT, W>(p);
+    if (blockIdx.x < x.pf_blocks) {   // uniform per workgroup
+        stage_ahead<NT, EXT, W>(p, x, lds);
+        return;
+    }
+    const LaneMap m = lane_map<NT, EXT, W>(p, blockIdx.x - x.pf_blocks);
 #ifdef UAVX_STAMPS
     unsigned long long stamps[8] = {};
     const bool stamp_on = true;
@@ -976,7 +1027,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 7 : 1) void step_ex_ke
     // state loads of the launch-wide read burst.  The wave's step counter comes through the scalar cache.
     uint4 rec = make_uint4(0, 0, 0, 0);
     if (m.active) rec = p.env_rec[m.e];
-    const uint32_t wave_count = p.wave_steps[blockIdx.x];
+    const uint32_t wave_count = p.wave_steps[m.wave];
     __builtin_amdgcn_sched_barrier(0);
     if (m.active) {
         // the command is requested BEFORE the state: load_agent ends in arithmetic on what it loaded (prev_distance), and a
@@ -999,7 +1050,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 7 : 1) void step_ex_ke
         // mates and would finish last (launch time = slowest wave): let it issue ahead of them for the rest
         // of its life; the mates lose only issue slots they had to spare.
         __builtin_amdgcn_s_setprio(3);
-        // the layout was normally drawn ahead of time by prefetch_kernel (16-byte copies); only a miss -- first use, a
+        // the layout was normally drawn ahead of time by a staging workgroup (16-byte copies); only a miss -- first use, a
         // changed seed / world, an episode shorter than one call -- draws here
         bool hit = false;
         uint4 tag = make_uint4(0, 0, 0, 0);
@@ -1217,38 +1268,6 @@ __global__ __launch_bounds__(kWave * W) void reset_kernel(MultiParams p, const u
     }
 }
 
-// Draws the layout of every env's NEXT episode that is not parked yet (or parked for something else: other seed, world
-// version, level) into the staging arrays.  Same mapping and the same reset_envs_wave as reset_kernel, outputs redirected.
-// Launched on the handle's side stream next to every n-th uavx_step_ex launch and joined after it: the serial accept /
-// reject chains of the envs that need a layout run in ONE launch per n steps (and beside the step where the runtime
-// overlaps the two) instead of at the tail of every step launch.  Safe against the concurrent step
-// launch: that launch only READS the staging arrays of an env it re-initialises, and it publishes the env's new episode
-// index (env_rec.y) after those reads have returned -- so this kernel either sees the old index (and finds the parked
-// layout still right: nothing to do) or the new one (and may overwrite a layout that has been consumed).
-template <int NT, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W) void prefetch_kernel(MultiParams p, uint32_t k0, uint32_t k1) {
-    using LDS = LdsT<EXT, W>;
-    __shared__ LDS lds;
-    const LaneMap m = lane_map<NT, EXT, W>(p);
-    uint32_t episode = 0;
-    bool need = false;
-    if (m.active) {
-        episode = p.env_rec[m.e].y & ~kRecEnded;   // the index the env's next reset draws with
-        need = !stage_hit(p.stage_tag[m.e], stage_want<EXT>(p, m.e, episode, k0, k1));
-    }
-    if (!group_any<W>(need)) return;
-    AgentRegs s = {};
-    reset_envs_wave<NT, EXT>(p, m, lds, need, episode, k0, k1, s, p.stage_body, nullptr);
-    if (need) {
-        p.stage_agent[m.a] = make_float4(s.x, s.y, s.tx, s.ty);
-        if (m.i == 0) {
-            uint4 tag = stage_want<EXT>(p, m.e, episode, k0, k1);
-            tag.w = (tag.w & ~0xFFu) | (EXT ? ((s.flags & kLevelMask) >> kLevelShift) : 0u);   // the level it drew
-            p.stage_tag[m.e] = tag;
-        }
-    }
-}
-
 // extension plumbing: level table upload, per-env level arrays, body records
 struct LevelTable { LevelParams l[UAVX_MAX_LEVELS]; };
 __global__ __launch_bounds__(64) void upload_levels_kernel(LevelParams *dst, LevelTable t) {
@@ -1377,13 +1396,9 @@ struct uavx_handle {
     void *wide_slab = nullptr;
     // configs[4] extension: scripted bodies and / or an installed curriculum select the EXT kernel variants
     int gw = 1;  // wavefronts per workgroup of the step / reset / observe launches (pick_group_waves)
-    // pre-drawn layouts: prefetch_kernel runs on `side` next to every prefetch_every-th auto-resetting uavx_step_ex launch
+    // layouts drawn ahead (stage_ahead): every auto-resetting uavx_step_ex launch carries ceil(G / prefetch_every) staging
+    // workgroups in front of its G env-workgroups
     int prefetch_every = 16;   // 0: off
-    uint64_t ex_calls = 0;
-    bool in_capture = false;           // the previous auto-resetting call was recorded into stream capture `capture_id`
-    unsigned long long capture_id = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ext = false;
     uavx_body_rule rule = {5.0, 128, 0, 0};
     LevelTable levels = {};
@@ -1518,13 +1533,6 @@ struct ObserveLaunch {
     uavx_handle *h; dim3 grid; hipStream_t st; float *obs;
     template <int NT, bool EXT, int W> void run() const {
         hipLaunchKernelGGL((observe_kernel<NT, EXT, W>), grid, dim3(kWave * W), 0, st, h->p, obs);
-    }
-};
-
-struct PrefetchLaunch {
-    uavx_handle *h; dim3 grid; hipStream_t st; uint32_t k0, k1;
-    template <int NT, bool EXT, int W> void run() const {
-        hipLaunchKernelGGL((prefetch_kernel<NT, EXT, W>), grid, dim3(kWave * W), 0, st, h->p, k0, k1);
     }
 };
 
@@ -1719,9 +1727,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.E = num_envs;
     p.env_offset = env_offset;
     h->ext = B > 0;
-    // pre-drawn layouts pay where drawing inside the step launch is expensive: from 8 slots per env on (A/B in
-    // profiles/r02_ab_notes.md: 8 + 16 bodies 37.1 -> 24.9 us per fused step; 4 agents 7.8 -> 8.6, so off there)
-    h->prefetch_every = (N + B >= 8) ? 16 : 0;
+    h->prefetch_every = 16;   // layouts drawn ahead by 1/16 of the env-workgroups' worth of staging workgroups per launch
     apply_body_rule(h);
     h->levels.l[0] = make_level(*cfg, nullptr, N, B);
 
@@ -1772,11 +1778,6 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.stage_body = reinterpret_cast<float4 *>(b + o_sbody);
     p.stage_tag = reinterpret_cast<uint4 *>(b + o_stag);   // zero-filled: no layout is valid yet
     p.world_version = 1;
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP;
-    }
     hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);  // level 0 = the config
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(0);
@@ -1789,9 +1790,6 @@ int uavx_destroy(uavx_handle *h) {
     if (!h) return UAVX_ERR_INVALID_ARG;
     if (h->slab) {
         DeviceGuard guard(h->device);
-        if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
         (void)hipFree(h->slab);
         if (h->wide_slab) (void)hipFree(h->wide_slab);
     }
@@ -1819,7 +1817,6 @@ int uavx_num_bodies(const uavx_handle *h) { return h ? h->p.B : -1; }
 int uavx_set_prefetch(uavx_handle *h, int every) {
     if (!h || every < 0) return UAVX_ERR_INVALID_ARG;
     h->prefetch_every = every;
-    h->ex_calls = 0;
     return UAVX_OK;
 }
 
@@ -2014,35 +2011,16 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.ended = a->ended; x.truncated = a->truncated;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
-    // auto-resetting call: draw the layouts of the next episodes BESIDE the step launch (side stream, forked after the
-    // work already queued on `stream`, joined back before this call returns control of `stream`; capturable)
+    // auto-resetting call: the launch carries staging workgroups that draw the layouts of the next episodes (stage_ahead)
     const bool resets = a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0;
     x.use_stage = (h->prefetch_every > 0 && resets) ? 1 : 0;
+    x.pf_blocks = 0; x.pf_groups = grid.x;
+    dim3 launch = grid;
     if (x.use_stage) {
-        // A call recorded into a stream capture runs once per REPLAY of the graph: the first recorded call of every capture
-        // carries the side launch (and the count restarts there), so a graph of fewer than `every` steps still draws
-        // ahead once per replay instead of never / always depending on where the call count happened to stand.
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        unsigned long long cid = 0;
-        if (hipStreamGetCaptureInfo(st, &cs, &cid) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-        if (cs == hipStreamCaptureStatusActive) {
-            if (!h->in_capture || cid != h->capture_id) { h->in_capture = true; h->capture_id = cid; h->ex_calls = 0; }
-        } else {
-            h->in_capture = false;
-        }
+        x.pf_blocks = (grid.x + (unsigned)h->prefetch_every - 1u) / (unsigned)h->prefetch_every;
+        launch.x = grid.x + x.pf_blocks;
     }
-    const bool stage = x.use_stage && (h->ex_calls++ % (uint64_t)h->prefetch_every) == 0;
-    if (stage) {
-        UAVX_HIP(h, hipEventRecord(h->ev_fork, st));
-        UAVX_HIP(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        dispatch(h, PrefetchLaunch{h, grid, h->side, x.seed_lo, x.seed_hi});
-        UAVX_HIP(h, hipGetLastError());
-    }
-    dispatch(h, StepExLaunch{h, grid, st, x, a});
-    if (stage) {
-        UAVX_HIP(h, hipEventRecord(h->ev_join, h->side));
-        UAVX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
-    }
+    dispatch(h, StepExLaunch{h, launch, st, x, a});
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }

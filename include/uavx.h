@@ -240,17 +240,17 @@ typedef struct {
  * per-env episode statistics (also by uavx_reset). */
 int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
 
-/* Pre-drawn layouts (default: every = 16 for handles with 8 or more slots per env, learners + bodies; off below that,
- * where drawing inside the step launch is cheap).  The start / target layout of an env's next episode depends only on
- * (seed, global env id, episode index, level rule), so every `every`-th uavx_step_ex call with an auto-reset policy or a
- * step cap also queues a kernel on a side stream of the handle -- forked after the work already in `stream`, joined back
- * into `stream` before the call returns, capturable in a hipGraph -- that draws the layouts of the episodes that will
- * start next; a step launch then re-initialises an env with 16-byte copies instead of running the serial accept / reject
- * chain of MUW:127-153 on one wavefront while the rest of the chip waits for it (profiles/r02_ab_notes.md).  A layout parked
- * for another seed / world / level, or an episode that ends before the next side launch, simply misses and is drawn in the
- * step launch as before: results are identical either way.  every = 0 switches the side kernel off.
- * Calls recorded into a stream capture: the first recorded call of each capture carries the side launch and the count restarts
- * there, so every replay of a graph of n steps draws ahead ceil(n / every) times wherever the call count stood before. */
+/* Layouts drawn ahead of time (default: every = 16).  The start / target layout of an env's next episode depends only on
+ * (seed, global env id, episode index, level rule), so every uavx_step_ex launch with an auto-reset policy or a step cap
+ * carries ceil(G / every) extra workgroups in front of its G env-workgroups: they step nothing, they look after one slice
+ * of the envs (the slice rotates with the handle's step count, a device-side counter: replays of a captured graph rotate
+ * like eager calls) and draw the layouts of the episodes that will start next into a staging area.  A step workgroup then
+ * re-initialises an env with 16-byte copies instead of running the serial accept / reject chain of MUW:127-153 on one
+ * wavefront while the rest of the chip waits for it; the chains of the staging workgroups start first and finish
+ * underneath the same launch (profiles/r02_ab_notes.md).  A layout parked for another seed / world / level, or a second
+ * episode end of the same env within `every` launches, simply misses and is drawn in the step workgroup as before:
+ * results are identical either way.  every = 0 switches staging off; every = 1 looks after every env in every launch.
+ * No second kernel, stream or event is involved: one launch per call, on `stream`. */
 int uavx_set_prefetch(uavx_handle *h, int every);
 
 /* Per-env statistics over the episodes ended so far (by auto-reset or uavx_reset):

@@ -99,7 +99,7 @@ def test_config5_combined_vs_oracle(amd, oracle_mod, prefetch):
     kw = dict(num_agents=L, num_bodies=B, body_speed=2.0, body_period=16, body_seed=3)
     env = amd.BatchedMultiUAVWorld2D(E, seed=21, env_offset=7, **kw)
     orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
-    env.set_prefetch(prefetch)   # pre-drawn layouts on a side stream vs. drawing inside the step launch: same results
+    env.set_prefetch(prefetch)   # layouts drawn ahead by staging workgroups (1/16 or all envs per launch) vs. in place: same results
     env.set_curriculum(small, lo=0, hi=1)
     orc.set_curriculum(small, lo=0, hi=1)
     mem = DeviceReplay(env, horizon=24)
@@ -338,10 +338,10 @@ def test_randomized_extension_shapes(amd, oracle_mod):
         env.close()
 
 
-def test_prefetch_side_kernel_on_a_caller_stream(amd, oracle_mod):
-    """uavx_step_ex queues its layout-prefetch kernel on a side stream of the handle, forked from and joined into the CALLER's
-    stream: drive everything from a non-default torch stream, prefetch on every call, no host synchronisation between the
-    calls of a burst -- results must still be the oracle's (an ordering hole would show as a stale or torn layout)."""
+def test_layout_staging_on_a_caller_stream(amd, oracle_mod):
+    """Everything driven from a non-default torch stream, every env's next layout re-staged in every launch (every = 1), no
+    host synchronisation between the calls of a burst -- results must still be the oracle's (an ordering hole between the
+    staging and the step workgroups of a launch would show as a stale or torn layout)."""
     import torch
     E, L, B = 2048, 8, 16
     kw = dict(num_agents=L, num_bodies=B, body_period=4, x_size=20.0, y_size=20.0, d_sense=8.0, collider_radius=0.5)
