@@ -36,10 +36,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6
 L3_BYTES = 256 * 2 ** 20       # Infinity Cache
 
 
-def algorithmic_bytes_per_env_step(n_agents, n_bodies=0):
+def algorithmic_bytes_per_env_step(n_agents, n_bodies=0, active_agents=None, active_bodies=None):
     """lean f32 SoA, 41 B read + 66 B write per agent-step + 24 B per-env counters; a scripted
-    body (BASELINE configs[4]) is a 16 B read + 16 B write record (no action, no observation / reward / done)."""
-    return 107 * n_agents + 24 + 32 * n_bodies
+    body (BASELINE configs[4]) is a 16 B read + 16 B write record (no action, no observation / reward / done).
+    Under a curriculum only the slots a level switches on count in full (mean over the levels, which envs draw uniformly):
+    a parked learner still has its observation / reward / done rows written (45 B) and nothing else, a body that is
+    switched off moves nothing."""
+    na = n_agents if active_agents is None else active_agents
+    nb = n_bodies if active_bodies is None else active_bodies
+    return 107 * na + 45 * (n_agents - na) + 24 + 32 * nb
 
 
 def measured_traffic(kernel_name, shape):
@@ -344,12 +349,18 @@ def main():
                                      **(dict(num_bodies=B) if B else {}))
         bytes_per_env_step = algorithmic_bytes_per_env_step(N, B)
         ext = bool(B or args.curriculum)    # the kernel variant with bodies / levels (runtime agent count)
+        bytes_note = ""
         if args.curriculum:
             n = args.curriculum
             f = lambda a, b, k: a + (b - a) * k / max(1, n - 1)
-            env.set_curriculum([dict(x_size=f(30.0, 60.0, k), y_size=f(30.0, 60.0, k), collider_radius=1.0, d_sense=f(10.0, 18.0, k),
-                                     n_active=max(1, round(f(N / 2, N, k))), b_active=round(f(B / 4, B, k))) for k in range(n)],
-                               lo=0, hi=n - 1)
+            levels = [dict(x_size=f(30.0, 60.0, k), y_size=f(30.0, 60.0, k), collider_radius=1.0, d_sense=f(10.0, 18.0, k),
+                           n_active=max(1, round(f(N / 2, N, k))), b_active=round(f(B / 4, B, k))) for k in range(n)]
+            env.set_curriculum(levels, lo=0, hi=n - 1)
+            na, nb = sum(l["n_active"] for l in levels) / n, sum(l["b_active"] for l in levels) / n
+            bytes_per_env_step = algorithmic_bytes_per_env_step(N, B, na, nb)
+            bytes_note = (f"; algorithmic bytes count the slots the curriculum switches on ({na:g} of {N} learners, {nb:g} of {B} bodies "
+                          f"on average over its {n} levels: {bytes_per_env_step:.0f} B per env-step instead of "
+                          f"{algorithmic_bytes_per_env_step(N, B)})")
         if args.fused:
             ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
             fused_kw = dict(polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
@@ -429,6 +440,8 @@ def main():
                 + ("fits the 256 MiB Infinity Cache: FETCH/WRITE_SIZE count fabric requests incl. L3 hits, so this point is "
                    "L3-resident, not HBM-streaming; see roofline_large for the HBM-sized batch" if ws < L3_BYTES else
                    "exceeds the 256 MiB Infinity Cache: HBM-streaming"))
+        if args.world == "multi":
+            note += bytes_note
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

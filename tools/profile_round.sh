@@ -1,8 +1,9 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/prof/<shape>/<pass>/ (run on the GPU box through gpurun), then
 #   python tools/summarize_profiles.py rNN   condenses it into profiles/.
-# usage: tools/profile_round.sh [calib] [ExN[+B][f] | uwE ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f uw1048576
-#        (+B: scripted bodies; trailing f: the fused uavx_step_ex path with polar actions, auto-reset and statistics)
+# usage: tools/profile_round.sh [calib] [ExN[+B][f][cL][r] | uwE ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f 65536x8+16fc4r uw1048576
+#        (+B: scripted bodies; f: the fused uavx_step_ex path with polar actions, auto-reset and statistics; cL: L-level
+#         curriculum; r: outputs into the on-device replay ring -- 65536x8+16fc4r is bench.py --cfg5)
 # Kernel trace and each counter group are separate runs (counter collection serialises and slows kernels); the
 # program itself follows `--` (no env / bash -c hop).  TCC has 4 counter slots per pass, SQ 8.
 set -e
@@ -32,10 +33,13 @@ for arg in "$@"; do
   if [[ "$arg" == uw* ]]; then   # uwE: the UAVWorld2D kernel on E envs
     BARGS="--world uw --envs ${arg#uw} --ring 8 --no-cpu-baseline --no-large"
   else
-    fused=""; a=$arg; [[ "$a" == *f ]] && { fused="--fused"; a=${a%f}; }
+    fused=""; a=$arg; extra=""
+    [[ "$a" == *r ]] && { extra="$extra --replay"; a=${a%r}; }                                  # ...r: outputs into the replay ring
+    [[ "$a" =~ c([0-9]+)$ ]] && { extra="$extra --curriculum ${BASH_REMATCH[1]}"; a=${a%c*}; }   # ...cL: L-level curriculum
+    [[ "$a" == *f ]] && { fused="--fused"; a=${a%f}; }
     shape=${a%%+*}; bodies=0; [[ "$a" == *+* ]] && bodies=${a##*+}
     E=${shape%%x*}; N=${shape##*x}
-    BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large $fused"
+    BARGS="--envs $E --agents $N --bodies $bodies --no-cpu-baseline --no-large $fused $extra"
   fi
   rocprofv3 --output-format csv --kernel-trace --stats -d $d/kt -o run -- python3 bench.py $BARGS --steps 1000 --warmup 100 > $d/kt.log 2>&1
   find $d/kt -name "*kernel_trace.csv" -delete; find $d/kt -name "*agent_info.csv" -delete   # keep the stats summary only (64 MiB merge limit)

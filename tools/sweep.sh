@@ -12,8 +12,10 @@ run --envs 65536 --agents 5
 run --envs 32768 --agents 10
 run --envs 16384 --agents 24
 run --envs 65536 --agents 24 --steps 500 --warmup 50 --ring 8   # all-learner N = 24 (runtime-N path, 3-wavefront workgroups)
-run --envs 65536 --agents 8 --bodies 16 --ring 16               # BASELINE configs[4] as designed: 8 learners + 16 scripted bodies
+run --envs 65536 --agents 8 --bodies 16 --ring 16               # BASELINE configs[4]'s world: 8 learners + 16 scripted bodies, bare step
 run --envs 65536 --agents 8 --bodies 16 --ring 16 --fused
+run --envs 65536 --cfg5 --ring 16                               # ... + 4-level randomized-reset curriculum + outputs into the replay ring
+run --envs 65536 --agents 8 --fused
 run --envs 4096 --agents 1
 run --envs 4096 --world uw
 run --envs 65536 --world uw
