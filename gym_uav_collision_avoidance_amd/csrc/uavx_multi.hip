@@ -962,17 +962,26 @@ __device__ unsigned int g_stamp_n;
 // or was drawn for something else, and runs their chains -- started first, they finish underneath the step workgroups of
 // the same launch.  An env is looked after once every S launches; one that ends two episodes within S launches misses and
 // draws in its step workgroup as before (same result either way).
-// Safe against the step workgroups of the same launch: those only READ the staging arrays of an env they re-initialise,
-// and publish the env's new episode index (env_rec.y) after those reads have returned -- a staging workgroup either sees
-// the old index (and finds the parked layout still right: nothing to do) or the new one (and may overwrite a layout that
-// has been consumed).
+// Safe against the step workgroups of the same launch: those read the staging arrays only of an env they re-initialise,
+// i.e. one whose record carried the "ended" mark when the launch began -- and exactly those envs are left alone here.  An
+// episode that ends DURING this launch sets the mark for the next launch; whether a staging workgroup sees it or not, the
+// index it would draw with is the one the next reset uses.
 template <int NT, bool EXT, int W, class LDS>
 __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtra &x, LDS &lds) {
     // the launch counter: env-workgroup 0's step count, which its step workgroup moves on at the END of every launch.  (A
     // staging workgroup that read it only after that -- dispatched 20 us late -- would look after the next slice instead:
     // harmless, every slice is as good as any other.  A shared arrival counter would make the rotation exact, but 512
     // same-address atomics per launch serialise at ~25 ns each.)
-    const uint32_t c = p.wave_steps[0];
+    uint32_t c;
+    if (W == 1) {
+        c = __builtin_amdgcn_readfirstlane(p.wave_steps[0]);
+    } else {   // ONE read per workgroup: its wavefronts must agree on the slice whatever the timing
+        uint32_t *slot = reinterpret_cast<uint32_t *>(lds.obs);
+        if (threadIdx.x == 0) *slot = p.wave_steps[0];
+        __syncthreads();
+        c = *slot;
+        __syncthreads();   // (the tile is reused further down)
+    }
     const uint32_t slices = (x.pf_groups + x.pf_blocks - 1u) / x.pf_blocks;
     const uint32_t w = (c % slices) * x.pf_blocks + blockIdx.x;
     if (w >= x.pf_groups) return;
@@ -980,8 +989,13 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
     uint32_t episode = 0;
     bool need = false;
     if (m.active) {
-        episode = p.env_rec[m.e].y & ~kRecEnded;   // the index the env's next reset draws with
-        need = !stage_hit(p.stage_tag[m.e], stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
+        // An env whose episode has ENDED is re-initialised by its step workgroup in this very launch, which reads the tag
+        // and the parked layout while we run: it is left alone here (nothing orders our stores against those reads inside
+        // a launch) and picked up by a later launch under its new episode index.  Every env looked after here is therefore
+        // one whose staging arrays nobody reads before the next kernel boundary.
+        const uint32_t y = p.env_rec[m.e].y;
+        episode = y & ~kRecEnded;                  // the index the env's next reset draws with
+        need = !(y & kRecEnded) && !stage_hit(p.stage_tag[m.e], stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
     }
     if (!group_any<W>(need)) return;
     __builtin_amdgcn_s_setprio(3);   // a serial chain the launch must not end up waiting for: issue ahead of the SIMD mates
