@@ -244,3 +244,19 @@ def test_checkpoint_written_in_the_reference_layout(tmp_path):
     back = load_reference_checkpoint(f, device="cpu")
     for a, b in zip(pol.state_dict().values(), back.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_bench_algorithmic_bytes_and_refusal_without_gpu():
+    """The per-env-step byte figures bench.py prices the roofline with and its refusal to run without a GPU."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.algorithmic_bytes_per_env_step(4) == 452 and bench.algorithmic_bytes_per_env_step(1) == 131
+    assert bench.algorithmic_bytes_per_env_step(8) == 880 and bench.algorithmic_bytes_per_env_step(8, 16) == 880 + 16 * 32
+    # a curriculum that switches on 6 of 8 learners and 10 of 16 bodies on average: parked learners only have their 45 B of outputs written
+    assert bench.algorithmic_bytes_per_env_step(8, 16, 6, 10) == 107 * 6 + 45 * 2 + 24 + 32 * 10
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
