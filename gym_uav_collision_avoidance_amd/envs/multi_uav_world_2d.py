@@ -8,7 +8,6 @@ the process-global `np.random` stream in the same order (MUW:126-153), so a seed
 same start/target layout as with the reference; the layout is then uploaded with uavx_set_state.
 """
 import colorsys
-import math
 
 import numpy as np
 import torch

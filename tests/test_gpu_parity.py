@@ -6,7 +6,7 @@ the circle)."""
 import numpy as np
 import pytest
 
-from golden_util import ANGLE_COLS, UW_ANGLE_COLS, fixture_names, load_fixture, obs_err, tie_agents
+from golden_util import UW_ANGLE_COLS, fixture_names, load_fixture, obs_err, tie_agents
 
 pytestmark = pytest.mark.gpu
 

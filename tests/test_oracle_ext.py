@@ -6,7 +6,6 @@ definition in include/uavx.h promises."""
 import os
 
 import numpy as np
-import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
