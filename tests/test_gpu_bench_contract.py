@@ -53,7 +53,7 @@ def test_driver_sized_run_is_a_pure_graph_replay():
     assert d["steps_executed"] == 3 + 5 + 10 * 20    # capture warm-up + warm-up + 5 wall-clock and 5 device-time regions (counted before roofline_steady runs)
     assert d["value"] > 7e9, d["value"]   # 20 x ~6.3 us of kernels + one graph launch; 9-10 G on a quiet box
     st = d["roofline_steady"]             # the same launches over 1000-step regions, next to the 20-step figure
-    assert st["steps"] == 1000 and st["frac"] >= d["roofline"]["frac"] and st["kernel_us"] > 3.0
+    assert st["steps"] == 1000 and st["frac"] >= 0.95 * d["roofline"]["frac"] and st["kernel_us"] > 3.0   # (5 % for box noise)
 
 
 def test_cfg5_as_designed_line():
