@@ -418,3 +418,37 @@ def test_uw_step_ex_auto_reset_vs_oracle(amd, oracle_mod, polar, cap):
     np.testing.assert_array_equal(_np(env.episode_stats()["episodes"]), orc.fin_counts[:, 0])
     np.testing.assert_array_equal(_np(env.episode_stats()["reached"]), orc.fin_counts[:, 2])
     env.close()
+
+
+def test_split_batch_chains_equal_the_undivided_batch(amd):
+    """sharding.SplitBatch: the batch as two handles with a stream each (the double-buffered trainer layout), stepped as
+    independent fused chains without any host synchronisation in between -- every env must come out exactly as in the
+    undivided batch (auto-resets included: Philox streams are keyed by global env id)."""
+    import torch
+    from gym_uav_collision_avoidance_amd.sharding import SplitBatch
+    E, N, T = 1001, 4, 90            # 501 + 500 envs
+    whole = amd.BatchedMultiUAVWorld2D(E, num_agents=N, seed=5, x_size=30.0, y_size=30.0)
+    sb = SplitBatch(amd.BatchedMultiUAVWorld2D, E, parts=2, num_agents=N, seed=5, x_size=30.0, y_size=30.0)
+    assert [c for _, c in sb.ranges] == [501, 500]
+    g = torch.Generator(device=whole.device).manual_seed(3)
+    acts = torch.rand((T, E, N, 2), generator=g, device=whole.device) * 2 - 1
+    kw = dict(polar=True, auto_reset="agent0_done", step_cap=25, track_returns=True)
+    o_w = whole.reset(seed=5).clone()
+    o_p = sb.reset(seed=5)
+    assert torch.equal(torch.cat(o_p), o_w)
+    outs = [[] for _ in sb.envs]
+    for k, env in enumerate(sb.envs):            # chain k runs ahead on its own stream, nothing waits for the other
+        off, cnt = sb.ranges[k]
+        with torch.cuda.stream(sb.streams[k]):
+            for t in range(T):
+                o, r, d, info = env.step_ex(acts[t, off:off + cnt], **kw)
+                outs[k].append((o.clone(), r.clone(), d.clone(), info["reset_mask"].clone(), info["truncated"].clone()))
+    sb.synchronize()
+    for t in range(T):
+        o, r, d, info = whole.step_ex(acts[t], **kw)
+        for j, name in enumerate(("obs", "rew", "done")):
+            assert torch.equal(torch.cat([outs[k][t][j] for k in range(2)]), (o, r, d)[j]), (t, name)
+        assert torch.equal(torch.cat([outs[k][t][3] for k in range(2)]), info["reset_mask"]), t
+        assert torch.equal(torch.cat([outs[k][t][4] for k in range(2)]), info["truncated"]), t
+    assert torch.equal(sb.metrics(), whole.metrics())
+    sb.close(); whole.close()
