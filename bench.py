@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      # same thing: starts the launcher line above as a child process
 
 One "step" = one launch of the fused HIP step kernel over the whole batch (all agents of all envs
 advanced once, MUW:177-241).  Workload = BASELINE.json configs[2], the configuration the metric is
@@ -316,6 +317,34 @@ def working_set_bytes(E, n_slots, n_learners, ring_len):
     return E * (n_slots * 40 + n_learners * (2 * 40 + 4 + 1) + ring_len * n_learners * 8) + E * 48
 
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`
+    as a child process and return its exit code.  Signals that end this process are passed on to the child's process
+    group so that a driver-side timeout does not leave ranks behind."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(proc.pid, signum)
+        except OSError:
+            pass
+    for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
+        signal.signal(sig, forward)
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,11 +384,16 @@ def main():
     if args.world == "uw" and (args.curriculum or args.replay or args.bodies):
         raise SystemExit("--curriculum / --replay / --bodies belong to --world multi")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU).  This process has
+        # not touched the GPU yet (importing torch does not initialise HIP) and never will: the ranks are CHILD processes
+        # (no exec from here), their stdout is ours, so rank 0's JSON line streams through, and we leave with their exit code.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher must start {args.gpus} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X; there is no CPU fallback for the env step path")
     # UAVX_REHEARSAL=1: several ranks share GPU 0 and talk over gloo (to rehearse the N>1 launch contract on

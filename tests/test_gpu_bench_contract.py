@@ -88,6 +88,24 @@ def test_two_rank_rehearsal():
     assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"])   # ... on every env of both shards
 
 
+def test_gpus_2_without_a_launcher():
+    """`python3 bench.py --gpus 2 ...` exactly as a driver would type it for the scaling curve, NOT wrapped in
+    torch.distributed.run: bench.py starts its two ranks itself (child process, before any GPU call in the parent),
+    rank 0's line comes through on stdout, exit code 0.  (Rehearsal: both ranks share the one GPU and talk over gloo.)"""
+    env = dict(os.environ, UAVX_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "8192"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]              # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["envs_per_gpu"] == 8192
+    assert d["config"]["parallelism"] == "env-index shard x2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+
+
 def test_rccl_code_path_with_one_rank():
     """The N>1 branch of bench.py on the real RCCL backend (communicator on the device, gather, barriers, hipGraph
     capture next to the RCCL watchdog thread) with a single rank: what a one-GPU box can exercise of it."""

@@ -260,3 +260,22 @@ def test_bench_algorithmic_bytes_and_refusal_without_gpu():
     if not torch.cuda.is_available():
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0"], capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver may run for the scaling curve) starts
+    torch.distributed.run itself as a child process and leaves with the child's exit code.  Without a GPU every rank
+    refuses to run: the refusal must be the RANKS' ("no CPU fallback"), printed by processes that carry WORLD_SIZE=2,
+    not a complaint of the parent about a missing launcher."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this test is tests/test_gpu_bench_contract.py::test_gpus_2_without_a_launcher")
+    env = dict(os.environ, UAVX_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    text = out.stderr + out.stdout
+    assert out.returncode != 0
+    assert "no CPU fallback" in text and "launcher must start" not in text, text[-2000:]
