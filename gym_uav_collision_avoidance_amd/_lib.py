@@ -12,12 +12,14 @@ OBS_DIM = 10
 UW_OBS_DIM = 4
 MAX_AGENTS = 64
 MAX_LEVELS = 16
+BODY_DIM = 6
+ABI_VERSION = 3
 FLAG_DONE, FLAG_COLLIDED, FLAG_VEL_F32, FLAG_INACTIVE = 1, 2, 4, 32
 F32, F64 = 0, 1
 
 # every symbol include/uavx.h declares (tests check the built library exports each of them)
 SYMBOLS = (
-    "uavx_version", "uavx_selftest", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
+    "uavx_version", "uavx_build_info", "uavx_selftest", "uavx_strerror", "uavx_create", "uavx_destroy", "uavx_last_error", "uavx_num_envs",
     "uavx_num_agents", "uavx_set_config", "uavx_set_body_rule", "uavx_num_bodies", "uavx_get_bodies", "uavx_set_bodies",
     "uavx_set_curriculum", "uavx_set_env_levels", "uavx_get_env_levels", "uavx_set_prefetch", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
     "uavx_set_state", "uavx_set_position_mode", "uavx_get_position_mode", "uavx_set_state_f64", "uavx_get_state_f64",
@@ -112,8 +114,8 @@ def build(force=False):
             if not force and os.path.exists(LIB_PATH) and _up_to_date():
                 return LIB_PATH
             tmp = f"libuavx.so.tmp{os.getpid()}"
-            proc = subprocess.run(["make", "-C", CSRC, "-B", f"OUT={tmp}"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                                  text=True)
+            proc = subprocess.run(["make", "-C", CSRC, "-B", f"OUT={tmp}", f"SRCHASH={source_hash()}"], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True)
             if proc.returncode != 0:
                 try:
                     os.unlink(os.path.join(CSRC, tmp))
@@ -127,7 +129,20 @@ def build(force=False):
 
 
 def _up_to_date():
+    """Is LIB_PATH the build of the sources in the tree?  By content: the library carries the hash of the sources it was
+    built from (uavx_build_info); file times say nothing after a checkout or a snapshot copy.  A library built by a
+    hand-run make (no hash) falls back to comparing file times."""
     import glob
+    import re
+    # read from the file, not through dlopen: a mapped library stays mapped, and a later CDLL of the rebuilt file under the
+    # same path would hand back the old one
+    with open(LIB_PATH, "rb") as f:
+        mark = re.search(rb"UAVX_SRC_HASH=([0-9a-f]*)\0", f.read())
+    if mark is None:
+        return False          # built before the marker existed
+    built_from = mark.group(1).decode()
+    if built_from:
+        return built_from == source_hash()
     srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + [
         os.path.join(os.path.dirname(_HERE), "include", "uavx.h"), os.path.join(CSRC, "Makefile")]
     return os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)
@@ -137,9 +152,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        # not built yet (fresh checkout): compile the HIP library once; this is a build, not a fallback, and a
-        # compile error is raised as such instead of being reported as "not built"
+    override = bool(os.environ.get("UAVX_LIB"))
+    if not os.path.exists(LIB_PATH) or (not override and not _up_to_date()):
+        # not built yet (fresh checkout), or older than its sources (the ABI structs grow between versions: a stale library
+        # with the same symbol names would be read with the wrong layout): compile the HIP library; this is a build, not a
+        # fallback, and a compile error is raised as such instead of being reported as "not built".  An explicit UAVX_LIB
+        # (A/B builds) is taken as it is and only has to pass the version check below.
         build()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -148,6 +166,10 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
     L.uavx_version.restype = i32
+    L.uavx_build_info.restype = ctypes.c_char_p
+    if L.uavx_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} speaks ABI version {L.uavx_version()}, this package binds version {ABI_VERSION}: "
+                           f"rebuild it (`make -B -C {CSRC}`)")
     L.uavx_selftest.argtypes = [i32, ctypes.POINTER(ctypes.c_uint64)]
     L.uavx_strerror.restype = ctypes.c_char_p
     L.uavx_strerror.argtypes = [i32]

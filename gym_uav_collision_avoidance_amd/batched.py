@@ -220,13 +220,14 @@ class BatchedMultiUAVWorld2D(_Base):
         _lib.check(self._L.uavx_set_prefetch(self._h, int(every)), self._h)
 
     def get_bodies(self):
-        """[E, B, 4] float32 {x, y, waypoint x, waypoint y}; a body switched off by its env's level sits at +inf."""
-        t = torch.empty((self.num_envs, self.num_bodies, 4), dtype=torch.float32, device=self.device)
+        """[E, B, 6] float32 {x, y, dx, dy, heading, legs}: position, displacement per env step, direction of travel, steps of
+        the current leg that move (include/uavx.h, uavx_set_body_rule); a body switched off by its env's level sits at +inf."""
+        t = torch.empty((self.num_envs, self.num_bodies, _lib.BODY_DIM), dtype=torch.float32, device=self.device)
         _lib.check(self._L.uavx_get_bodies(self._h, t.data_ptr(), self._stream()), self._h)
         return t
 
     def set_bodies(self, records):
-        t = torch.as_tensor(records, device=self.device).to(torch.float32).reshape(self.num_envs, self.num_bodies, 4).contiguous()
+        t = torch.as_tensor(records, device=self.device).to(torch.float32).reshape(self.num_envs, self.num_bodies, _lib.BODY_DIM).contiguous()
         _lib.check(self._L.uavx_set_bodies(self._h, t.data_ptr(), self._stream()), self._h)
         torch.cuda.current_stream(self.device).synchronize()
 

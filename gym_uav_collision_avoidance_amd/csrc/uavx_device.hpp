@@ -114,6 +114,28 @@ __device__ __forceinline__ float atan2_fast(float y, float x) {
     return copysignf(r, y);
 }
 
+// The same reduction and polynomial with an IEEE division instead of v_rcp_f32: every operation is correctly rounded, so
+// the CPU test oracle restates it bit for bit (its atan2_leg).  Used where an angle becomes STATE (the heading
+// a scripted body keeps for a whole leg); off the per-step path, so its cost does not matter.
+__device__ __forceinline__ float atan2_exact(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const bool big = mn > 0.41421356237f * mx;
+    const float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    den = (mx == 0.f) ? 1.f : den;
+    const float t = num / den;
+    const float z = t * t;
+    float pl = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    pl = fmaf(pl, z, 1.99777106478e-1f);
+    pl = fmaf(pl, z, -3.33329491539e-1f);
+    float r = fmaf(pl * z, t, t);
+    r = big ? r + 0.78539816339744830962f : r;
+    r = (ay > ax) ? 1.57079632679489661923f - r : r;
+    r = (x < 0.f) ? kPi - r : r;
+    return copysignf(r, y);
+}
+
 // v_max_f64 / v_min_f64 against a wave-uniform limit, as ONE instruction each.  fmax() / fmin() make hipcc canonicalise
 // every operand first (v_max_f64 x, x, x -- also the limits held in scalar registers, again at every use): 20 float64
 // instructions for the 12 clamps of one agent step, and a float64 instruction costs two float32 issue slots.  For

@@ -31,6 +31,8 @@
 //              running returns; touched by reset / step_ex only), episode statistics (fin_*).
 // BASELINE configs[4] extension (scripted bodies, per-env curriculum levels; EXT kernel variants): see MultiParams and
 // include/uavx.h; lanes stay one per LEARNER there and the bodies are extra rows of the env's LDS neighbour tile.
+// A body is a position (float2, read + written while it moves) and a leg record {dx, dy, heading, legs} (float4, read
+// only between two waypoint changes): 24 B read + 8 B written per body-step, two float32 additions of arithmetic.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -106,7 +108,8 @@ struct MultiParams {
     float body_step;              // float32(speed * tau): metres per env step
     uint32_t body_k0, body_k1;    // Philox key of the waypoint streams
     int n_levels, level_lo, level_hi;
-    float4 *body;                 // [E*B] {x, y, wx, wy}
+    float2 *body_pos;             // [E*B] {x, y}; +inf for a body its env's level switches off
+    float4 *body_leg;             // [E*B] {dx, dy, heading, legs}: displacement per env step, direction of travel, steps of the leg that move
     uint8_t *lvl_cur, *lvl_next;  // [E] level in force / level assigned for the next reset
     const LevelParams *levels;    // [UAVX_MAX_LEVELS] device table, read only while a curriculum is installed (n_levels > 0)
     // ---- pre-drawn layouts (uavx_step_ex auto-reset; see stage_ahead) ----
@@ -115,9 +118,14 @@ struct MultiParams {
     // re-initialises the env then copies 16 B per slot instead of running the serial accept / reject chain on one wavefront while the
     // rest of the chip waits for it.  stage_tag says exactly what a parked layout was drawn for; anything else is a miss
     // and falls back to drawing in the step launch.
-    float4 *stage_agent;          // [E*L] {sx, sy, tx, ty}
-    float4 *stage_body;           // [E*B] {x, y, wx, wy}
-    uint4 *stage_tag;             // [E] {episode index, seed lo, seed hi, level | world version << 8 | valid << 31}
+    // TWO parked layouts per env, for its next episode and the one after (slot = episode index & 1, slot-major arrays): the
+    // layout of episode y + 1 is already there when episode y's is consumed, so an env only ever draws in place when two of its
+    // episodes end within the two or three launches it takes to park a layout again
+    float4 *stage_agent;          // [2][E*L] {sx, sy, tx, ty}
+    float2 *stage_bpos;           // [2][E*B] as body_pos
+    float4 *stage_bleg;           // [2][E*B] as body_leg
+    uint4 *stage_tag;             // [2][E] {episode index, seed lo, seed hi, level | world version << 8 | valid << 31}
+    int magic_s;                  // 65536 / (L + B) + 1: thread / (L + B) of a staging workgroup by multiply-shift
     uint32_t world_version;       // bumped by every call that changes what a layout depends on (config, curriculum, body rule)
 };
 constexpr uint32_t kStageValid = 0x80000000u;
@@ -234,6 +242,13 @@ using Lds = LdsT<false>;
 
 // World limits of this lane's env: kernel arguments, or (EXT) the level its flags word names -- two 16-byte loads from a
 // table every lane of the chip shares, i.e. an L1/L2 hit whose latency hides under the kinematics.
+// d_sense alone (all the neighbour scan needs): the other seven limits are fetched AFTER the scan, where they are used --
+// per-lane values loaded at the top of the step stayed in eight registers across the scan, the most register-hungry stretch
+template <bool EXT>
+__device__ __forceinline__ float sense_limit(const MultiParams &p, uint32_t flags) {
+    if (EXT && p.n_levels > 0) return p.levels[(flags & kLevelMask) >> kLevelShift].sq_sense;
+    return p.sq_sense;
+}
 template <bool EXT>
 __device__ __forceinline__ WorldLims world_lims(const MultiParams &p, uint32_t flags) {
     WorldLims w;
@@ -292,7 +307,7 @@ struct Neigh {
 };
 
 template <int NT, bool STEP, class LDS>
-__device__ __forceinline__ Neigh scan_neighbours_exact(const WorldLims &w, const LaneMap &m, const LDS &lds, float nx,
+__device__ __forceinline__ Neigh scan_neighbours_exact(float sq_sense, const LaneMap &m, const LDS &lds, float nx,
                                                        float ny) {
     const int N = NT ? NT : m.nslots;
     Neigh r;
@@ -310,9 +325,9 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(const WorldLims &w, const
             const float bx = dxo * dxo, by = dyo * dyo;
             const float so = bx + by;
             const float ss = (j < m.i) ? sn : so;      // j<i already moved this step, j>i not yet
-            r.step_sq_min = fminf(r.step_sq_min, (ss < w.sq_sense) ? ss : INFINITY);
+            r.step_sq_min = fminf(r.step_sq_min, (ss < sq_sense) ? ss : INFINITY);
         }
-        const float dn = (sn < w.sq_sense) ? sqrt_rn(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
+        const float dn = (sn < sq_sense) ? sqrt_rn(sn) : INFINITY;  // AG:51-52 (IEEE-rounded sqrt)
         const bool lt1 = dn < r.d1, lt2 = dn < r.d2;
         r.d2 = lt1 ? r.d1 : (lt2 ? dn : r.d2);
         r.j2 = lt1 ? r.j1 : (lt2 ? j : r.j2);
@@ -361,11 +376,11 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
 }
 
 template <int NT, bool STEP, class LDS>
-__device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneMap &m, const LDS &lds, float nx,
+__device__ __forceinline__ Neigh scan_neighbours(float sq_sense, const LaneMap &m, const LDS &lds, float nx,
                                                  float ny) {
-    if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);
+    if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);
     const int N = NT ? NT : m.nslots;
-    if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);  // <= 4 others: nothing to save
+    if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);  // <= 4 others: nothing to save
     const float4 *row = &lds.pos[m.rbase];
     uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
     float step_min = INFINITY;
@@ -418,27 +433,39 @@ __device__ __forceinline__ Neigh scan_neighbours(const WorldLims &w, const LaneM
             visit((uint32_t)c, la, other(c, la));
             c++;
         }
-        // bodies sit above every learner and move after them (never "already moved"): the Gauss-Seidel select folds away
+        // bodies sit above every learner and have moved before any of them: ONE squared distance serves the collision test
+        // and the observation, and the Gauss-Seidel select folds away (rows {x, y, x, y}: 8-byte reads of the upper half)
+        auto body = [&](uint32_t c, int r) {
+            const float2 q = *reinterpret_cast<const float2 *>(&row[r].z);
+            const float dxn = q.x - nx, dyn = q.y - ny;
+            const float ax = dxn * dxn, ay = dyn * dyn;
+            const float sn = ax + ay;
+            if (STEP) step_min = fminf(step_min, sn);
+            uint32_t key;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(sn), "v"(keep), "s"(c));
+            k3 = med3_u32(k2, k3, key);
+            k2 = med3_u32(k1, k2, key);
+            k1 = min(k1, key);
+        };
         for (; c + 1 < N - 1; c += 2) {
-            const float4 qa = row[c + 1], qb = row[c + 2];
-            visit((uint32_t)c, false, qa);
-            visit((uint32_t)c + 1u, false, qb);
+            body((uint32_t)c, c + 1);
+            body((uint32_t)c + 1u, c + 2);
         }
-        if (c < N - 1) visit((uint32_t)c, false, row[c + 1]);
+        if (c < N - 1) body((uint32_t)c, c + 1);
     }
     // N > 5: at least five neighbours were visited, so k1..k3 are real keys
-    const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(w.sq_sense) >> 6;
+    const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(sq_sense) >> 6;
     const bool near_tie = (t2 - t1 <= 1u && t1 <= ts) || (t3 - t2 <= 1u && t2 <= ts);
-    if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(w, m, lds, nx, ny);
+    if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);
     const int c1 = (int)(k1 & 63u), c2 = (int)(k2 & 63u);
     const int j1 = c1 + (c1 >= m.i ? 1 : 0), j2 = c2 + (c2 >= m.i ? 1 : 0);
     const float4 q1 = row[j1], q2 = row[j2];
     const float ex1 = q1.z - nx, ey1 = q1.w - ny, ex2 = q2.z - nx, ey2 = q2.w - ny;
     const float mx1 = ex1 * ex1, my1 = ey1 * ey1, mx2 = ex2 * ex2, my2 = ey2 * ey2;
     const float s1 = mx1 + my1, s2 = mx2 + my2;
-    const bool in1 = s1 < w.sq_sense, in2 = s2 < w.sq_sense;  // AG:52
+    const bool in1 = s1 < sq_sense, in2 = s2 < sq_sense;  // AG:52
     Neigh r;
-    r.step_sq_min = (step_min < w.sq_sense) ? step_min : INFINITY;
+    r.step_sq_min = (step_min < sq_sense) ? step_min : INFINITY;
     r.d1 = in1 ? sqrt_rn(s1) : INFINITY;
     r.d2 = in2 ? sqrt_rn(s2) : INFINITY;
     r.j1 = in1 ? j1 : -1;
@@ -518,70 +545,76 @@ __device__ __forceinline__ void store_obs_block(const MultiParams &p, const Lane
     group_sync<LDS::kW>();
 }
 
-// configs[4] extension: the scripted bodies of this lane's env (include/uavx.h, uavx_set_body_rule).  Body b is handled
-// by the env's learner lane b % L in trip b / L: loaded (16 B), moved when MOVE, staged into its neighbour row
-// {old, new} + heading, stored back (16 B).  A body that does not take part (b >= the level's b_active) is staged at +inf.
-//   from_lds  the record is taken from the env's LDS row {x, y, wx, wy}, where reset_envs_wave left it (it also stored it);
-//   frozen    the env was re-initialised by this call: its bodies only show up, they do not move.
+// configs[4] extension: a body starts a leg at (x, y) towards waypoint (wx, wy) -- include/uavx.h, uavx_set_body_rule; float32,
+// no FMA, IEEE division and square root, restated bit for bit by the oracle (body_leg).  Off the per-step path (reset, and one
+// env step in `period`).
+__device__ __forceinline__ float4 make_leg(float body_step, float x, float y, float wx, float wy) {
+    const float dx = wx - x, dy = wy - y;
+    const float d = norm32(dx, dy);
+    float4 leg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d > 0.f) {
+        const float sc = body_step / d;
+        leg.x = dx * sc; leg.y = dy * sc;
+        leg.w = floorf(d / body_step);   // body_step == 0 (static obstacle): +inf legs of zero displacement
+    }
+    leg.z = atan2_exact(dy, dx);
+    return leg;
+}
+
+// configs[4] extension: the scripted bodies of this lane's env.  Body b is handled by the env's learner lane b % L in trip
+// b / L: position (8 B) and leg record (16 B) loaded, moved when MOVE -- the bodies move BEFORE the learners of the env's
+// sequential loop, so the collision tests and the observations of this step both see the new positions --, staged into its
+// neighbour row {x, y, x, y} + heading, position stored back (8 B) if it moved.  A body that does not take part (b >= the
+// level's b_active) is staged at +inf.
+//   ready   the env was re-initialised by this call: its bodies' rows were staged by the reset path, they do not move.
 template <bool MOVE, class LDS>
-__device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap &m, LDS &lds, uint32_t flags, bool from_lds,
-                                             bool frozen, uint32_t steps, uint32_t ep_draw) {
+__device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap &m, LDS &lds, uint32_t flags, bool ready,
+                                             uint32_t steps, uint32_t ep_draw) {
     const int L = p.N;
     const bool leveled = p.n_levels > 0;
     const LevelParams *lv = &p.levels[(flags & kLevelMask) >> kLevelShift];   // read only when a curriculum is installed
     const int b_active = m.active ? (leveled ? lv->b_active : p.B) : 0;
-    auto fetch = [&](int k) {
+    const uint32_t kk = steps & (uint32_t)p.body_pmask;     // steps of the current leg that lie behind the body
+    const bool retarget = MOVE && steps != 0u && kk == 0u;  // a new waypoint every `period` steps
+    const float kf = (float)kk;
+#pragma unroll 1
+    for (int k = 0; k < p.kb; k++) {
         const int b = k * L + m.i;
-        const bool on = m.active && b < p.B && b < b_active;
-        float4 r = make_float4(INFINITY, INFINITY, 0.f, 0.f);
-        if (on) r = from_lds ? lds.pos[m.rbase + L + b] : p.body[m.e * (uint32_t)p.B + (uint32_t)b];
-        return r;
-    };
-    auto work = [&](int k, float4 r) {
-        const int b = k * L + m.i;
-        const bool valid = m.active && b < p.B;
+        const bool valid = m.active && b < p.B && !ready;
         const bool on = valid && b < b_active;
-        const int row = m.rbase + L + (valid ? b : 0);
         const uint32_t gi = m.e * (uint32_t)p.B + (uint32_t)b;
-        const float ox = r.x, oy = r.y;
-        if (MOVE && on && !frozen) {
-            if (steps != 0u && (steps & (uint32_t)p.body_pmask) == 0u) {  // a new waypoint every `period` steps
-                const ResetCandidates c = reset_candidates((uint64_t)p.env_offset + m.e, (uint32_t)(L + b),
-                                                           0x80000000u | (steps >> p.body_pshift), ep_draw, p.body_k0,
-                                                           p.body_k1, leveled ? lv->lox : p.lox, leveled ? lv->loy : p.loy,
-                                                           leveled ? lv->hix : p.hix, leveled ? lv->hiy : p.hiy);
-                r.z = c.sx; r.w = c.sy;
-            }
-            const float dx = r.z - r.x, dy = r.w - r.y;
-            const float d = norm32(dx, dy);
-            if (d > p.body_step) {          // body_step metres straight towards the waypoint (float32, no FMA)
-                const float sc = p.body_step / d;
-                const float mx = dx * sc, my = dy * sc;
-                r.x = r.x + mx; r.y = r.y + my;
-            } else {
-                r.x = r.z; r.y = r.w;
-            }
+        float2 q = make_float2(INFINITY, INFINITY);
+        float4 leg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) { q = p.body_pos[gi]; leg = p.body_leg[gi]; }
+        if (on && retarget) {
+            const ResetCandidates c = reset_candidates((uint64_t)p.env_offset + m.e, (uint32_t)(L + b),
+                                                       0x80000000u | (steps >> p.body_pshift), ep_draw, p.body_k0,
+                                                       p.body_k1, leveled ? lv->lox : p.lox, leveled ? lv->loy : p.loy,
+                                                       leveled ? lv->hix : p.hix, leveled ? lv->hiy : p.hiy);
+            leg = make_leg(p.body_step, q.x, q.y, c.sx, c.sy);
+            p.body_leg[gi] = leg;
+        }
+        if (MOVE && on && kf < leg.w) {
+            q.x = q.x + leg.x; q.y = q.y + leg.y;
+            p.body_pos[gi] = q;
         }
         if (valid) {
-            lds.pos[row] = on ? make_float4(ox, oy, r.x, r.y) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-            lds.theta[row] = atan2_fast(r.w - r.y, r.z - r.x);   // heading: towards the waypoint
+            lds.pos[m.rbase + L + b] = make_float4(q.x, q.y, q.x, q.y);
+            lds.theta[m.rbase + L + b] = leg.z;
         }
-        if (MOVE && on && !frozen) p.body[gi] = r;
-    };
-#pragma unroll 1
-    for (int k = 0; k < p.kb; k++) work(k, fetch(k));
+    }
 }
 
 // One env step for this lane's agent (state in registers).  MUW:177-241.
 //   frozen: the env was re-initialised by this call (auto-reset); the agent only observes.
 //   EXT: env_steps / ep_draw = the env's step count before this step and the episode index its reset drew with
-//        (scripted bodies); bodies_from_lds: see stage_bodies.
+//        (scripted bodies); frozen envs had their bodies' rows staged by the reset path.
 template <int NT, bool EXT, class LDS>
 __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &m, LDS &lds, AgentRegs &s, double ax,
                                            double ay, int evaluate, float o[10], float &rew, uint32_t &done_out,
                                            uint32_t &reach_ev, uint32_t &coll_ev, bool frozen = false,
-                                           uint32_t env_steps = 0, uint32_t ep_draw = 0, bool bodies_from_lds = false) {
-    const WorldLims w = world_lims<EXT>(p, s.flags);
+                                           uint32_t env_steps = 0, uint32_t ep_draw = 0) {
+    const float sq_sense = sense_limit<EXT>(p, s.flags);
     const bool was_done = (s.flags & UAVX_FLAG_DONE) != 0;
     const bool parked = EXT && (s.flags & kFlagInactive) != 0;  // extension: learner switched off by its env's level
     if (!frozen) s.flags &= ~(kFlagPrevOvr | kFlagJustDone);  // from here on prev_distance is the natural one again
@@ -599,13 +632,14 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
     const float theta = atan2_fast((float)s.vy, (float)s.vx);   // MUW:63,185
     const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);    // MUW:184-186 == MUW:69-71
 
-    if (EXT && p.B > 0) stage_bodies<true>(p, m, lds, s.flags, bodies_from_lds, frozen, env_steps, ep_draw);
     if (m.active) {
         lds.pos[m.rbase + m.i] = make_float4(ox, oy, s.x, s.y);   // a parked learner sits at +inf
         lds.theta[m.rbase + m.i] = theta;
     }
+    if (EXT && p.B > 0) stage_bodies<true>(p, m, lds, s.flags, frozen, env_steps, ep_draw);
     group_sync<LDS::kW>();
-    const Neigh nb = scan_neighbours<NT, true>(w, m, lds, s.x, s.y);
+    const Neigh nb = scan_neighbours<NT, true>(sq_sense, m, lds, s.x, s.y);
+    const WorldLims w = world_lims<EXT>(p, s.flags);
 
     // reward shaping, MUW:188-195 (float32, reciprocals instead of divisions; |error| << 1e-5)
     const float inv_init = __builtin_amdgcn_rcpf(s.init_d);
@@ -670,8 +704,11 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 
 // One env step per launch (the RL loop's shape: the policy runs between two launches).
 // (with bodies the allocator lands on 65 VGPRs = 7 wavefronts per SIMD; asking for 8 gives 62 without a spill)
+#ifndef UAVX_STEPB
+#define UAVX_STEPB 8
+#endif
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 8 : 1) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
+__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
                                                          float *__restrict__ obs_out, float *__restrict__ rew_out,
                                                          uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
@@ -715,8 +752,8 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 8 : 1) void step_kerne
 // One round of the accept/reject chain: does any agent of the workgroup clash, and which is the lowest-indexed clashing
 // agent of MY env?  One wavefront per workgroup: a ballot.  Several: an LDS min per env (scratch in the obs tile, which is
 // only used at the very end of a launch) and a workgroup-wide OR.  Returns false when nobody clashes (uniform).
-template <class LDS>
-__device__ __forceinline__ bool lowest_clash(const LaneMap &m, LDS &lds, unsigned long long group, bool clash, int &low) {
+template <class LDS, class MAP>
+__device__ __forceinline__ bool lowest_clash(const MAP &m, LDS &lds, unsigned long long group, bool clash, int &low) {
     if (LDS::kW == 1) {
         const unsigned long long bits = __ballot(clash);
         const unsigned long long mine = (bits >> m.base) & group;     // clashing agents of my env
@@ -754,13 +791,16 @@ __device__ __forceinline__ bool too_close(float sq_two_r, float ax, float ay, fl
 // EXT (include/uavx.h, curriculum + bodies): the env first takes its level; learners >= the level's n_active are parked;
 // the level's bodies then draw their start points in slot order by the same chain, trip by trip (body b belongs to
 // lane b % L, trip b / L), against the learners' accepted starts and the lower-indexed bodies, and take waypoint 0.
-// Body records are stored by this function; the rows of the bodies that take part stay in LDS as {x, y, wx, wy}.
-// body_out / lvl_out: where the body records and the env's level go -- the live arrays (p.body, p.lvl_cur), or the staging
-// area of a pre-drawn layout (p.stage_body, nullptr: the level then only travels in s.flags).
+// Body records (position + leg 0) are stored by this function, and the bodies' neighbour rows of a re-initialised env are
+// left in LDS in their staged form ({x, y, x, y} + heading; +inf for a body that does not take part): stage_bodies skips them.
+// bpos_out / bleg_out / lvl_out: where the body records and the env's level go -- the live arrays (p.body_pos, p.body_leg,
+// p.lvl_cur), or the staging area of a pre-drawn layout (p.stage_bpos, p.stage_bleg, nullptr: the level then only travels
+// in s.flags).
+constexpr int kChainRows = 4;   // rows of accepted points a clash test reads per trip (8-byte halves of the rows: the points only)
 template <int NT, bool EXT, class LDS>
 __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, LDS &lds, bool go,
                                                 uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s,
-                                                float4 *body_out, uint8_t *lvl_out) {
+                                                float2 *bpos_out, float4 *bleg_out, uint8_t *lvl_out) {
     const int N = NT ? NT : p.N;
     float4 *row = &lds.pos[m.rbase];
     const uint64_t ge = (uint64_t)p.env_offset + m.e;
@@ -805,13 +845,15 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                 const float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
                 clash = phase ? too_close(sq2r, qx, qy, c.sx, c.sy) : false;                       // MUW:146
 #pragma unroll 1
-                for (int j0 = 0; j0 < m.i; j0 += 4) {  // four rows per trip (LDS round trips bound this loop)
-                    float4 o[4];
+                for (int j0 = 0; j0 < m.i; j0 += kChainRows) {  // several rows per trip (LDS round trips bound this loop)
+                    float2 o[kChainRows];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) o[u] = row[min(j0 + u, m.i - 1)];
+                    for (int u = 0; u < kChainRows; u++) {
+                        const float4 *r4 = &row[min(j0 + u, m.i - 1)];
+                        o[u] = *reinterpret_cast<const float2 *>(phase ? &r4->z : &r4->x);
+                    }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        clash = clash || too_close(sq2r, phase ? o[u].z : o[u].x, phase ? o[u].w : o[u].y, qx, qy);  // MUW:135,151
+                    for (int u = 0; u < kChainRows; u++) clash = clash || too_close(sq2r, o[u].x, o[u].y, qx, qy);  // MUW:135,151
                 }
             }
             int low;   // lowest-indexed clashing agent of my env (>= N: none)
@@ -849,15 +891,15 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                     // slowest resetting wave of a launch is what the whole launch waits for
                     const int cnt = nl + b;
 #pragma unroll 1
-                    for (int j0 = 0; j0 < cnt; j0 += 4) {
-                        float4 o[4];
+                    for (int j0 = 0; j0 < cnt; j0 += kChainRows) {
+                        float2 o[kChainRows];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
+                        for (int u = 0; u < kChainRows; u++) {
                             const int j = min(j0 + u, cnt - 1);
-                            o[u] = row[j < nl ? j : N + (j - nl)];
+                            o[u] = *reinterpret_cast<const float2 *>(&row[j < nl ? j : N + (j - nl)].x);
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) clash = clash || too_close(sq2r, o[u].x, o[u].y, qx, qy);
+                        for (int u = 0; u < kChainRows; u++) clash = clash || too_close(sq2r, o[u].x, o[u].y, qx, qy);
                     }
                 }
                 int low;
@@ -872,14 +914,18 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
                 group_sync<LDS::kW>();
             }
             if (go && b < p.B) {
-                float4 rec = make_float4(INFINITY, INFINITY, 0.f, 0.f);    // a body that does not take part
+                float2 q = make_float2(INFINITY, INFINITY);    // a body that does not take part
+                float4 leg = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (on) {
                     const ResetCandidates w0 = reset_candidates(ge, (uint32_t)slot, 0x80000000u, episode & ~kRecEnded, p.body_k0,
                                                                 p.body_k1, lox, loy, hix, hiy);
-                    rec = make_float4(qx, qy, w0.sx, w0.sy);
-                    row[slot] = rec;
+                    q = make_float2(qx, qy);
+                    leg = make_leg(p.body_step, qx, qy, w0.sx, w0.sy);   // leg 0: towards waypoint 0
                 }
-                body_out[m.e * (uint32_t)p.B + (uint32_t)b] = rec;
+                row[slot] = make_float4(q.x, q.y, q.x, q.y);
+                lds.theta[m.rbase + slot] = leg.z;
+                bpos_out[m.e * (uint32_t)p.B + (uint32_t)b] = q;
+                bleg_out[m.e * (uint32_t)p.B + (uint32_t)b] = leg;
             }
         }
     }
@@ -946,69 +992,292 @@ __device__ __forceinline__ void polar_to_command(const MultiParams &p, float a0,
 }
 
 #ifdef UAVX_STAMPS
-__device__ unsigned long long g_stamps[8 * 4096];
+// diagnostic build (tools/exp_stamps.py): every wavefront of a uavx_step_ex launch logs {start, mid, end, kind | xcc << 8 | block << 16}
+__device__ unsigned long long g_stamps[8 * 16384];
 __device__ unsigned int g_stamp_n;
-#define STAMP(k) do { if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(k) do { stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ __forceinline__ void stamp_log(const unsigned long long *st, unsigned int kind) {
+    if ((threadIdx.x & 63) != 0) return;
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned int k = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;   // a slot per wavefront: no shared counter to queue on
+    if (k < 16384) {
+        for (int t = 0; t < 7; t++) g_stamps[8 * k + t] = st[t];
+        g_stamps[8 * k + 7] = 0x80000000ull << 32 | kind | ((xcc & 15u) << 8) | ((unsigned long long)blockIdx.x << 16);
+    }
+    if (k == 0) g_stamp_n = gridDim.x * (blockDim.x / 64);
+}
 #else
 #define STAMP(k)
 #endif
 
 // Layouts drawn ahead of time, inside the step launch.  The layout of an env's NEXT episode is a pure function of (seed,
 // global env, episode index, level rule); re-initialising an env from a parked layout costs 16-byte copies, drawing it in
-// place costs a serial accept / reject chain on ONE wavefront (a few thousand instructions with scripted bodies) that the
-// whole launch then waits for.  So the first pf_blocks workgroups of every auto-resetting uavx_step_ex launch draw instead of
-// stepping: launch c looks after slice c mod S of the env-workgroups (S = ceil(G / pf_blocks), c = the handle's step count
-// in device memory, so replays of a captured graph rotate like eager calls do), finds the envs whose parked layout is missing
-// or was drawn for something else, and runs their chains -- started first, they finish underneath the step workgroups of
-// the same launch.  An env is looked after once every S launches; one that ends two episodes within S launches misses and
-// draws in its step workgroup as before (same result either way).
-// Safe against the step workgroups of the same launch: those read the staging arrays only of an env they re-initialise,
-// i.e. one whose record carried the "ended" mark when the launch began -- and exactly those envs are left alone here.  An
-// episode that ends DURING this launch sets the mark for the next launch; whether a staging workgroup sees it or not, the
-// index it would draw with is the one the next reset uses.
+// place costs a serial accept / reject chain on ONE wavefront that the whole launch then waits for (with 16 scripted bodies:
+// 8 us for a lucky env running alone on its SIMD, 19 us for the unluckiest of the ~100 envs that reset in a launch).  So the
+// first pf_blocks workgroups of every auto-resetting uavx_step_ex launch draw instead of stepping.  A launch is as long as its
+// slowest wavefront, so what matters is how long ONE staging workgroup lives, not how many there are (per-wavefront
+// timelines: tools/exp_stamps.py, profiles/r03_ab_notes.md):
+//   * SCAN: a staging workgroup looks at one window of 64 W envs, a lane each (the window rotates with the handle's step
+//     count, a device-side counter: replays of a captured graph rotate like eager calls; at 65 536 envs the 512 staging
+//     workgroups of a launch cover half the batch): record and the tags of the env's two parked layouts, one memory round trip;
+//   * an env keeps TWO parked layouts, for its next episode (index y, slot y & 1) and the one after: consuming one leaves
+//     the other in place, so how soon a layout is parked again (two or three launches) is not critical and an env draws
+//     in place only at first use, after a changed seed / world, or when two of its episodes end within those few launches;
+//   * DRAW: the first floor(64 W / S) missing layouts the scan found are drawn at once with ONE LANE PER SLOT of the
+//     neighbour model (S = L + B lanes per layout, learners and bodies alike): every slot draws its candidate in the same
+//     Philox call and the chain is one fixed-point iteration over all start points followed by one over the learners'
+//     targets (round 2 mapped a lane per learner and walked the bodies in ceil(B / L) sequential trips, each with its own
+//     Philox calls and clash loops); what a window holds beyond that is found again when the window comes round (every
+//     other launch), so a full invalidation -- creation, a new seed or world -- is worked off at pf_blocks floor(64 W / S)
+//     layouts per launch while the envs that need one meanwhile draw in place as before (same result either way).
+// Safe against the step workgroups of the SAME launch: those read the staging arrays only of an env they re-initialise, i.e.
+// one whose record carried the "ended" mark when the launch began, and only slot y & 1 of it -- and exactly that slot of
+// exactly those envs is left alone here (nothing orders our stores against another workgroup's loads inside a launch); their
+// other slot (episode y + 1) may be drawn at any time.  INVARIANT this rests on: a step workgroup clears the mark (its
+// env_rec store, the last thing it does) only after every load it made from the staging arrays has returned -- the record's
+// new "ended" bit is computed from the step's done flags, which are computed from the loaded layout, so the store cannot be
+// issued earlier; a staging workgroup that sees the mark cleared (and the episode index moved on) may therefore overwrite
+// the consumed slot at once.  (tests/test_gpu_ext.py steps with caps of 1 and 2 and staging in every launch for that overlap.)
+struct StageMap {   // lane-per-slot mapping of a staging workgroup (the fields lowest_clash() reads are named as in LaneMap)
+    int i, base, g, rbase;
+    bool active;
+    uint32_t e;
+};
 template <int NT, bool EXT, int W, class LDS>
 __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtra &x, LDS &lds) {
-    // the launch counter: env-workgroup 0's step count, which its step workgroup moves on at the END of every launch.  (A
-    // staging workgroup that read it only after that -- dispatched 20 us late -- would look after the next slice instead:
-    // harmless, every slice is as good as any other.  A shared arrival counter would make the rotation exact, but 512
-    // same-address atomics per launch serialise at ~25 ns each.)
-    uint32_t c;
-    if (W == 1) {
-        c = __builtin_amdgcn_readfirstlane(p.wave_steps[0]);
-    } else {   // ONE read per workgroup: its wavefronts must agree on the slice whatever the timing
-        uint32_t *slot = reinterpret_cast<uint32_t *>(lds.obs);
-        if (threadIdx.x == 0) *slot = p.wave_steps[0];
-        __syncthreads();
-        c = *slot;
-        __syncthreads();   // (the tile is reused further down)
-    }
-    const uint32_t slices = (x.pf_groups + x.pf_blocks - 1u) / x.pf_blocks;
-    const uint32_t w = (c % slices) * x.pf_blocks + blockIdx.x;
-    if (w >= x.pf_groups) return;
-    const LaneMap m = lane_map<NT, EXT, W>(p, w);
-    uint32_t episode = 0;
+#ifdef UAVX_STAMPS
+    unsigned long long stamps[7] = {};
+    STAMP(0);
+#endif
+    const int L = NT ? NT : p.N;
+    const int S = EXT ? p.nslots : L;                 // lanes per layout
+    const int epg = (kWave * W) / S;                  // layouts a staging workgroup draws
+    // ---- scan: one window of 64 W envs, a lane each ----
+    const uint32_t span = kWave * W;
+    const uint32_t windows = ((uint32_t)p.E + span - 1u) / span;
+    // Which window?  Staging workgroup b owns the windows b, b + pf_blocks, b + 2 pf_blocks ... and looks at one of them per
+    // launch, picked by the low bits of the clock: any window is as good as any other (results never depend on what is parked),
+    // and a rotation that counted launches would put a dependent memory round trip (the handle's step count lives in device
+    // memory, so that graph replays move on like eager calls) in front of the scan of EVERY staging workgroup -- which a
+    // displaced step workgroup is waiting behind.  With two parked layouts per env an env that has to wait a few launches
+    // longer for its turn loses nothing.
+    const uint32_t turns = (windows + x.pf_blocks - 1u) / x.pf_blocks;
+    const uint32_t turn = __builtin_amdgcn_readfirstlane((uint32_t)(__builtin_amdgcn_s_memtime() >> 7)) % turns;
+    const uint32_t se = ((blockIdx.x + turn * x.pf_blocks) % windows) * span + threadIdx.x;
+    uint32_t want_ep = 0;
     bool need = false;
-    if (m.active) {
-        // An env whose episode has ENDED is re-initialised by its step workgroup in this very launch, which reads the tag
-        // and the parked layout while we run: it is left alone here (nothing orders our stores against those reads inside
-        // a launch) and picked up by a later launch under its new episode index.  Every env looked after here is therefore
-        // one whose staging arrays nobody reads before the next kernel boundary.
-        const uint32_t y = p.env_rec[m.e].y;
-        episode = y & ~kRecEnded;                  // the index the env's next reset draws with
-        need = !(y & kRecEnded) && !stage_hit(p.stage_tag[m.e], stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
+    if (se < (uint32_t)p.E) {
+        const uint32_t y = p.env_rec[se].y;
+        const uint32_t ep = y & ~kRecEnded;
+        const uint4 t0 = p.stage_tag[se], t1 = p.stage_tag[(uint32_t)p.E + se];
+        const uint4 ta = (ep & 1u) ? t1 : t0, tb = (ep & 1u) ? t0 : t1;      // tags of the slots of episodes ep / ep + 1
+        const bool miss_a = !(y & kRecEnded) && !stage_hit(ta, stage_want<EXT>(p, se, ep, x.seed_lo, x.seed_hi));
+        const bool miss_b = !stage_hit(tb, stage_want<EXT>(p, se, (ep + 1u) & ~kRecEnded, x.seed_lo, x.seed_hi));
+        need = miss_a || miss_b;
+        want_ep = miss_a ? ep : ((ep + 1u) & ~kRecEnded);
     }
-    if (!group_any<W>(need)) return;
-    __builtin_amdgcn_s_setprio(3);   // a serial chain the launch must not end up waiting for: issue ahead of the SIMD mates
-    AgentRegs s = {};
-    reset_envs_wave<NT, EXT>(p, m, lds, need, episode, x.seed_lo, x.seed_hi, s, p.stage_body, nullptr);
+    // the level table (at most 16 x 80 B) rides the same round trip into LDS: the chain then reads its env's box from there
+    // instead of from memory (a dependent load behind the level draw)
+    // (16 levels x 5 float4 = 80 rows behind the 64 rows the chain of a one-wavefront workgroup works on; EXT kernels have 192)
+    constexpr int kLvlF4 = (int)(sizeof(LevelParams) / 16);
+    constexpr bool kLvlLds = EXT && W == 1 && LDS::kRows >= kWave + UAVX_MAX_LEVELS * kLvlF4;
+    if (kLvlLds && p.n_levels > 0) {
+#pragma unroll
+        for (int t = (int)threadIdx.x; t < UAVX_MAX_LEVELS * kLvlF4; t += kWave)
+            if (t < p.n_levels * kLvlF4) lds.pos[kWave + t] = reinterpret_cast<const float4 *>(p.levels)[t];
+    }
+    // the first epg of them become this workgroup's jobs (which ones does not matter)
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds.obs);        // job list: word 0 = count, job g = {env, episode} in words 1 + 2 g, 2 + 2 g
+    if (threadIdx.x == 0) cnt[0] = 0u;
+    group_sync<W>();
     if (need) {
-        p.stage_agent[m.a] = make_float4(s.x, s.y, s.tx, s.ty);
-        if (m.i == 0) {
-            uint4 tag = stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi);
-            tag.w = (tag.w & ~0xFFu) | (EXT ? ((s.flags & kLevelMask) >> kLevelShift) : 0u);   // the level it drew
-            p.stage_tag[m.e] = tag;
+        const uint32_t k = atomicAdd(cnt, 1u);
+        if ((int)k < epg) { cnt[1 + 2 * k] = se; cnt[2 + 2 * k] = want_ep; }
+    }
+    group_sync<W>();
+    const int n = min((int)cnt[0], epg);
+    if (n == 0) {
+#ifdef UAVX_STAMPS
+        STAMP(1); STAMP(2);
+        stamp_log(stamps, 10u);   // scanned, nothing to draw
+#endif
+        return;
+    }
+    // ---- the chain, one lane per slot ----
+    StageMap m;
+    uint32_t episode = 0;
+    {
+        const int lane = threadIdx.x;
+        const int g = (lane * p.magic_s) >> 16;       // floor(lane / S) for lane < 256 (host test)
+        m.i = lane - g * S;
+        m.g = g < n ? g : 0;
+        m.active = g < n;
+        m.base = m.active ? (g * S) & (kWave - 1) : 0;
+        m.rbase = m.active ? g * S : 0;
+        m.e = m.active ? cnt[1 + 2 * g] : 0u;
+        episode = m.active ? cnt[2 + 2 * g] : 0u;
+    }
+    const bool go = m.active;
+    group_sync<W>();   // (the job list lives in words the chain's scratch reuses)
+    STAMP(1);
+    __builtin_amdgcn_s_setprio(3);   // a serial chain the launch must not end up waiting for: issue ahead of the SIMD mates
+    const uint32_t k0 = x.seed_lo, k1 = x.seed_hi;
+    const uint64_t ge = (uint64_t)p.env_offset + m.e;
+    const unsigned long long group = (S >= 64) ? ~0ull : ((1ull << S) - 1ull);
+    const bool learner = m.i < L;
+    // Every Philox stream whose counter is known up front runs in ONE rolled loop (four independent multiply chains fill each
+    // other's latency; called one after the other they were four loops of dependent multiplies): the slot's first and second
+    // candidates (attempts 0 and 1: most layouts need a redraw somewhere, few slots need two), the env's level, and -- bodies --
+    // waypoint 0.  Further attempts of a slot are drawn on demand.
+    uint32_t cw[4][4];
+    {
+        const uint32_t e_lo = (uint32_t)ge, e_hi = (uint32_t)(ge >> 32) & 0xFFFFu;
+        uint32_t st[4][4] = {{e_lo, e_hi | ((uint32_t)m.i << 16), 0u, episode},             // candidates, attempt 0
+                             {e_lo, e_hi | ((uint32_t)m.i << 16), 1u, episode},             // candidates, attempt 1
+                             {e_lo, e_hi | (0xFFFFu << 16), 0u, episode},                   // level of the episode (pseudo-slot 0xFFFF)
+                             {e_lo, e_hi | ((uint32_t)m.i << 16), 0x80000000u, episode}};   // waypoint 0 (bodies; key = the body seed)
+        uint32_t ka0 = k0, ka1 = k1, kb0 = p.body_k0, kb1 = p.body_k1;
+#pragma unroll 1
+        for (int r = 0; r < 10; r++) {   // Philox4x32-10, the rounds of reset_words()
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t p0 = (uint64_t)0xD2511F53u * st[q][0];
+                const uint64_t p1 = (uint64_t)0xCD9E8D57u * st[q][2];
+                const uint32_t n0 = (uint32_t)(p1 >> 32) ^ st[q][1] ^ (q == 3 ? kb0 : ka0);
+                const uint32_t n2 = (uint32_t)(p0 >> 32) ^ st[q][3] ^ (q == 3 ? kb1 : ka1);
+                st[q][1] = (uint32_t)p1; st[q][3] = (uint32_t)p0; st[q][0] = n0; st[q][2] = n2;
+            }
+            ka0 += 0x9E3779B9u; ka1 += 0xBB67AE85u; kb0 += 0x9E3779B9u; kb1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) cw[q][k] = st[q][k];
+    }
+    STAMP(3);
+    double lox = p.lox, loy = p.loy, hix = p.hix, hiy = p.hiy;
+    float sq2r = p.sq_two_r;
+    uint32_t lvl = 0;
+    int nl = L, nb = EXT ? p.B : 0;
+    if (EXT && p.n_levels > 0) {   // MUW:116 extended: the env takes its level first (every lane of the env computes the same one)
+        if (go) {
+            lvl = (p.level_lo >= 0) ? (uint32_t)p.level_lo + __umulhi(cw[2][0], (uint32_t)(p.level_hi - p.level_lo + 1)) : (uint32_t)p.lvl_next[m.e];
+            lvl = min(lvl, (uint32_t)(p.n_levels - 1));
+        }
+        const LevelParams *lv = kLvlLds ? reinterpret_cast<const LevelParams *>(&lds.pos[kWave]) + lvl : &p.levels[lvl];
+        lox = lv->lox; loy = lv->loy; hix = lv->hix; hiy = lv->hiy;
+        sq2r = lv->sq_two_r;
+        nl = lv->n_active; nb = lv->b_active;
+    }
+    const double bx = hix - lox, by = hiy - loy, inv32 = 1.0 / 4294967296.0;
+    auto point = [&](uint32_t wx, uint32_t wy, float &px, float &py) {   // lo + (hi - lo) * U cast to float32, as reset_candidates()
+        px = (float)(lox + bx * ((double)wx * inv32));
+        py = (float)(loy + by * ((double)wy * inv32));
+    };
+    const bool part = go && (learner ? m.i < nl : m.i - L < nb);   // this lane's slot takes part in the episode
+    float4 *row = &lds.pos[m.rbase];
+    ResetCandidates c = {INFINITY, INFINITY, INFINITY, INFINITY};    // a slot that does not take part never clashes with anyone
+    if (part) { point(cw[0][0], cw[0][1], c.sx, c.sy); point(cw[0][2], cw[0][3], c.tx, c.ty); }
+    if (go) row[m.i] = make_float4(c.sx, c.sy, c.tx, c.ty);
+    group_sync<LDS::kW>();
+    STAMP(4);
+#pragma unroll 1
+    for (int phase = 0; phase < 2; phase++) {  // 0: all start points in slot order (MUW:126-137, bodies after learners), 1: targets MUW:140-153
+        uint32_t attempt = 0;
+        const bool mine = part && (phase == 0 || learner);
+        const int below = phase ? min(m.i, L) : m.i;     // lower-indexed slots whose accepted point mine must keep clear of
+        float qx = phase ? c.tx : c.sx, qy = phase ? c.ty : c.sy;
+        // which lower-indexed slots this one is too close to: a bit each.  The whole row of tests is made ONCE; a redraw
+        // changes one point of the env, so afterwards every lane re-tests against that point only.
+        unsigned long long cm = 0ull;
+        bool self = mine && phase && too_close(sq2r, qx, qy, c.sx, c.sy);                          // MUW:146
+        if (mine) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < below; j0 += kChainRows) {
+                float2 o[kChainRows];
+#pragma unroll
+                for (int u = 0; u < kChainRows; u++) {
+                    const float4 *r4 = &row[min(j0 + u, below - 1)];
+                    o[u] = *reinterpret_cast<const float2 *>(phase ? &r4->z : &r4->x);
+                }
+#pragma unroll
+                for (int u = 0; u < kChainRows; u++)
+                    if (j0 + u < below && too_close(sq2r, o[u].x, o[u].y, qx, qy)) cm |= 1ull << (j0 + u);  // MUW:135,151
+            }
+        }
+#pragma unroll 1
+        for (;;) {
+            int low;   // lowest-indexed clashing slot of my env (everything below it is final, everything above keeps its candidate)
+            if (!lowest_clash<LDS>(m, lds, group, mine && (self || cm != 0ull), low)) break;
+            const bool redraw = mine && m.i == low;
+            group_sync<LDS::kW>();
+            if (redraw) {
+                float rx, ry;
+                if (++attempt == 1u) {
+                    point(phase ? cw[1][2] : cw[1][0], phase ? cw[1][3] : cw[1][1], rx, ry);
+                } else {
+                    const ResetCandidates r = reset_candidates(ge, (uint32_t)m.i, attempt, episode, k0, k1, lox, loy, hix, hiy);
+                    rx = phase ? r.tx : r.sx; ry = phase ? r.ty : r.sy;
+                }
+                qx = rx; qy = ry;
+                if (phase) { c.tx = rx; c.ty = ry; row[m.i].z = rx; row[m.i].w = ry; self = too_close(sq2r, rx, ry, c.sx, c.sy); }
+                else { c.sx = rx; c.sy = ry; row[m.i].x = rx; row[m.i].y = ry; }
+            }
+            group_sync<LDS::kW>();
+            if (W == 1) {
+                // everybody re-tests against the ONE point of its env that moved: slots above it update that bit of theirs, the
+                // slots below it answer for the redrawn slot's own row of tests (the test is symmetric) through a ballot
+                const bool any_low = low < S;
+                const float4 *r4 = &row[any_low ? low : 0];
+                const float2 np = *reinterpret_cast<const float2 *>(phase ? &r4->z : &r4->x);
+                const bool t = mine && any_low && m.i != low && too_close(sq2r, np.x, np.y, qx, qy);
+                const unsigned long long bits = __ballot(t && m.i < low);
+                if (any_low && m.i > low) cm = (cm & ~(1ull << low)) | ((unsigned long long)t << low);
+                if (redraw) cm = (bits >> m.base) & ((1ull << low) - 1ull);
+            } else if (mine) {   // an env may span two wavefronts: the full row of tests again
+                cm = 0ull;
+#pragma unroll 1
+                for (int j0 = 0; j0 < below; j0++) {
+                    const float4 *r4 = &row[j0];
+                    const float2 o = *reinterpret_cast<const float2 *>(phase ? &r4->z : &r4->x);
+                    if (too_close(sq2r, o.x, o.y, qx, qy)) cm |= 1ull << j0;
+                }
+            }
         }
     }
+    STAMP(5);
+    if (go) {
+        const uint32_t sl = episode & 1u;   // the slot of this episode's layout
+        if (learner) {   // a parked learner sits at +inf with target 0 (what reset_envs_wave leaves in its record)
+            p.stage_agent[(sl * (uint32_t)p.E + m.e) * (uint32_t)L + (uint32_t)m.i] =
+                part ? make_float4(c.sx, c.sy, c.tx, c.ty) : make_float4(INFINITY, INFINITY, 0.f, 0.f);
+        } else if (EXT) {
+            float2 q = make_float2(INFINITY, INFINITY);    // a body that does not take part
+            float4 leg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (part) {
+                float wx, wy;
+                point(cw[3][0], cw[3][1], wx, wy);
+                q = make_float2(c.sx, c.sy);
+                leg = make_leg(p.body_step, c.sx, c.sy, wx, wy);   // leg 0: towards waypoint 0
+            }
+            const uint32_t gi = (sl * (uint32_t)p.E + m.e) * (uint32_t)p.B + (uint32_t)(m.i - L);
+            p.stage_bpos[gi] = q;
+            p.stage_bleg[gi] = leg;
+        }
+    }
+    // the tag goes last, behind every store of the layout it vouches for (it is read by a LATER launch, across a kernel
+    // boundary; the order only matters for whoever inspects the arrays while this launch runs: nobody does)
+    group_sync<W>();
+    if (go && m.i == 0) {
+        uint4 tag = stage_want<EXT>(p, m.e, episode, k0, k1);
+        tag.w = (tag.w & ~0xFFu) | (EXT ? lvl : 0u);   // the level it drew
+        p.stage_tag[(episode & 1u) * (uint32_t)p.E + m.e] = tag;
+    }
+#ifdef UAVX_STAMPS
+    STAMP(2);
+    stamp_log(stamps, 13u);   // drew layouts
+#endif
 }
 
 // uavx_step_ex: the step launch plus the trainer loop's bookkeeping (polar action conversion,
@@ -1017,21 +1286,25 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
 // took the variant with bodies from 83 to 72 VGPRs and the N = 8 one from 89 to 79; with the staging path (stage_ahead) in the
 // same kernel the variant with bodies is bounded at 6 wavefronts per SIMD (74 VGPRs, no spill; 7 = 72 VGPRs with scratch
 // reloads in the hot path: 22.3 -> 23.8 us).  The same kind of bound on the N = 8 variant spills in its hot path, not applied.
+#ifndef UAVX_EXB
+#define UAVX_EXB 8
+#endif
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 6 : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                             int evaluate, float *__restrict__ obs_out,
                                                             float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
     const int N = NT ? NT : p.N;
+#ifndef UAVX_X_NOSTAGE
     if (blockIdx.x < x.pf_blocks) {   // uniform per workgroup
         stage_ahead<NT, EXT, W>(p, x, lds);
         return;
     }
+#endif
     const LaneMap m = lane_map<NT, EXT, W>(p, blockIdx.x - x.pf_blocks);
 #ifdef UAVX_STAMPS
-    unsigned long long stamps[8] = {};
-    const bool stamp_on = true;
+    unsigned long long stamps[7] = {};
     STAMP(0);
 #endif
     AgentRegs s = {};
@@ -1053,66 +1326,103 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 6 : 1) void step_ex_ke
     const bool do_reset = (rec.y & kRecEnded) != 0;
     const uint32_t episode = rec.y & ~kRecEnded;
     uint32_t steps_v = wave_count - rec.x;
-    float2 run = make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w));
     // Register budget (the variants with 8 agents / bodies sit at the 64-VGPR edge of 8 wavefronts per SIMD): a
     // re-initialised env's record is written straight over the loaded one (`s`), and what the statistics fold needs is
     // read back from `rec` and memory at the END of the launch, by the (rare) lanes that need it.
     const bool wave_resets = group_any<W>(do_reset);   // uniform over the workgroup
-    STAMP(1);
     if (wave_resets) {  // wave-uniform: at least one env of this wave starts a new episode
         // A wave that re-initialises an env has a few hundred more instructions to issue than its three SIMD
         // mates and would finish last (launch time = slowest wave): let it issue ahead of them for the rest
         // of its life; the mates lose only issue slots they had to spare.
         __builtin_amdgcn_s_setprio(3);
-        // the layout was normally drawn ahead of time by a staging workgroup (16-byte copies); only a miss -- first use, a
-        // changed seed / world, an episode shorter than one call -- draws here
+        // The layout was normally drawn ahead of time by a staging workgroup (16-byte copies); only a miss -- first use, a
+        // changed seed / world, an episode that ended within two or three launches of its start -- draws here.
+        // Everything the parked layout consists of is requested together with its tag, before the tag is looked at: the
+        // wavefront is one memory round trip behind its mates instead of five (record -> tag -> agents -> bodies, trip by
+        // trip), and a launch is as long as its slowest wavefront.
         bool hit = false;
         uint4 tag = make_uint4(0, 0, 0, 0);
+        float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 bq0 = make_float2(0.f, 0.f), bq1 = bq0;
+        float4 bl0 = make_float4(0.f, 0.f, 0.f, 0.f), bl1 = bl0;
+        // the parked layout of episode `episode` lives in slot episode & 1 of the (slot-major) staging arrays
+        const uint32_t sl = episode & 1u;
+        const uint32_t sbase = sl * (uint32_t)p.E * (uint32_t)p.B + m.e * (uint32_t)p.B;   // first staged body of this env
         if (do_reset && x.use_stage) {
-            tag = p.stage_tag[m.e];
+            tag = p.stage_tag[sl * (uint32_t)p.E + m.e];
+            st = p.stage_agent[sl * (uint32_t)p.E * (uint32_t)N + m.a];
+            if (EXT) {   // the first two body trips (all of them up to B = 2 L); further ones below
+                if (m.i < p.B) { bq0 = p.stage_bpos[sbase + (uint32_t)m.i]; bl0 = p.stage_bleg[sbase + (uint32_t)m.i]; }
+                if (N + m.i < p.B) { bq1 = p.stage_bpos[sbase + (uint32_t)(N + m.i)]; bl1 = p.stage_bleg[sbase + (uint32_t)(N + m.i)]; }
+            }
             hit = stage_hit(tag, stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
         }
-        if (group_any<W>(do_reset && !hit))
-            reset_envs_wave<NT, EXT>(p, m, lds, do_reset && !hit, episode, x.seed_lo, x.seed_hi, s, p.body, p.lvl_cur);
+        const uint32_t hit_lvl = tag.w & 0xFFu;
+        if (EXT && hit) {   // the bodies of a parked layout: staged -> live, and into the env's LDS rows (frees their registers first)
+            if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)hit_lvl;
+            auto place = [&](int k, float2 q, float4 leg) {
+                const int b = k * N + m.i;
+                if (b < p.B) {
+                    const uint32_t gi = m.e * (uint32_t)p.B + (uint32_t)b;
+                    p.body_pos[gi] = q;
+                    p.body_leg[gi] = leg;
+                    lds.pos[m.rbase + N + b] = make_float4(q.x, q.y, q.x, q.y);
+                    lds.theta[m.rbase + N + b] = leg.z;
+                }
+            };
+            place(0, bq0, bl0);
+            place(1, bq1, bl1);
+#pragma unroll 1
+            for (int k = 2; k < p.kb; k++) {
+                const int b = k * N + m.i;
+                const uint32_t gi = sbase + (uint32_t)min(b, p.B - 1);
+                place(k, p.stage_bpos[gi], p.stage_bleg[gi]);
+            }
+        }
+#ifndef UAVX_X_NOMISS
+        if (group_any<W>(do_reset && !hit)) {
+            // The accept / reject chain needs some forty registers of its own.  Inlined into the step with the loaded state
+            // and command alive across it, it set the register count of the WHOLE kernel (74 with scripted bodies: 6
+            // wavefronts per SIMD instead of 8).  So nothing loaded at the top of the launch is carried across it: a wavefront
+            // that draws a layout in place reads the command and the state of its other envs AGAIN afterwards -- one more
+            // memory round trip on that (rare) wavefront instead of 10 registers on every wavefront of every launch.
+            const bool draw = do_reset && !hit;
+            AgentRegs t = {};
+            reset_envs_wave<NT, EXT>(p, m, lds, draw, episode, x.seed_lo, x.seed_hi, t, p.body_pos, p.body_leg, p.lvl_cur);
+            asm volatile("" ::: "memory");   // (the loads below must not be folded into the ones at the top)
+            AgentRegs r = {};
+            ax = 0.0; ay = 0.0;
+            if (m.active) {
+                load_action<ACT64>(actions, m.a, ax, ay);
+                if (!do_reset) load_agent(p, m.a, r);
+            }
+            s = draw ? t : r;
+        }
+#endif
         if (hit) {
-            const float4 st = p.stage_agent[m.a];
             s.x = st.x; s.y = st.y; s.tx = st.z; s.ty = st.w;
             s.vx = 0.0; s.vy = 0.0; s.flags = 0;                 // MUW:120-123
             bool parked = false;
             if (EXT) {
-                const uint32_t lvl = tag.w & 0xFFu;
-                parked = p.n_levels > 0 && m.i >= p.levels[lvl].n_active;
-                s.flags = (lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
-                if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)lvl;
-#pragma unroll 1
-                for (int k = 0; k < p.kb; k++) {   // the bodies' records: staged -> live, and into the env's LDS rows
-                    const int b = k * N + m.i;
-                    if (b < p.B) {
-                        const float4 r = p.stage_body[m.e * (uint32_t)p.B + (uint32_t)b];
-                        p.body[m.e * (uint32_t)p.B + (uint32_t)b] = r;
-                        lds.pos[m.rbase + N + b] = r;
-                    }
-                }
+                parked = p.n_levels > 0 && m.i >= p.levels[hit_lvl].n_active;
+                s.flags = (hit_lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
             }
             s.init_d = s.prev_d = parked ? INFINITY : norm32(s.tx - s.x, s.ty - s.y);  // MUW:154-155
         }
         if (do_reset) {
             p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, s.flags};
             steps_v = 0;                                           // MUW:166
-            run = make_float2(0.f, 0.f);
         }
     }
-    STAMP(2);
+    STAMP(1);
     const uint32_t flags_in = s.flags;
-    STAMP(3);
     if (x.action_mode == UAVX_ACTION_POLAR) polar_to_command(p, (float)ax, (float)ay, ax, ay);
     float o[10], rew;
     uint32_t dn, re, ce;
     // a freshly re-initialised env draws its bodies' waypoints with the episode index `episode`, a running one with the
     // index its own reset used (one less than the stored one)
     step_agent<NT, EXT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset, steps_v,
-                        (episode - (do_reset ? 0u : 1u)) & ~kRecEnded, do_reset);
-    STAMP(4);
+                        (episode - (do_reset ? 0u : 1u)) & ~kRecEnded);
     // episode end test for the NEXT call (test_sac_multi.py:67,112,116)
     bool all_done;
     if (W == 1) {
@@ -1132,6 +1442,10 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 6 : 1) void step_ex_ke
         if (m.active) lds.theta[m.rbase + m.i] = do_reset ? 0.f : rew * (1.0f - (float)dn);  // test_sac_multi.py:157
         group_sync<LDS::kW>();
     }
+    // The observation tile leaves FIRST: its ten registers per lane are free for the bookkeeping below, and the 40 B per
+    // agent of write-through stores drain underneath it.  (The tile never overlaps the theta rows the score sum below reads:
+    // separate arrays, or -- with scripted bodies -- the first 2 560 B of a union whose theta rows start at byte 3 072.)
+    store_obs_block<NT>(p, m, lds, o, obs_out);
     if (m.active) {
         if (!(EXT && (s.flags & kFlagInactive))) store_agent(p, m.a, s, flags_in);
         else if (do_reset) { p.pos[m.a] = make_float2(s.x, s.y); p.vel[m.a] = make_double2(0.0, 0.0); }  // parked at +inf
@@ -1141,6 +1455,12 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 6 : 1) void step_ex_ke
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
         if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
         if (m.i == 0) {
+            // The env record is read AGAIN here by the one lane that rewrites it, instead of being carried through the step
+            // in four registers of every lane (nothing has written it since the load at the top of the launch): the step
+            // with scripted bodies fits 64 VGPRs that way, i.e. 8 wavefronts per SIMD and ONE resident round for the 8 192
+            // wavefronts of a 65 536-env launch (6 per SIMD = 1.4 rounds, the second one mostly idle: +2 us).
+            const uint4 rec = p.env_rec[m.e];
+            float2 run = do_reset ? make_float2(0.f, 0.f) : make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w));
             const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;
             const bool terminal = (x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
                                   (x.reset_policy == UAVX_RESET_ALL_DONE && all_done);      // test_sac_multi.py:112,116
@@ -1166,17 +1486,9 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? 6 : 1) void step_ex_ke
             if (out.x != rec.x || out.y != rec.y || out.z != rec.z || out.w != rec.w) p.env_rec[m.e] = out;
         }
     }
-    store_obs_block<NT>(p, m, lds, o, obs_out);
 #ifdef UAVX_STAMPS
-    STAMP(5);
-    if (m.lane == 0 && (wave_resets || (blockIdx.x % 64 == 0))) {
-        const unsigned int k = atomicAdd(&g_stamp_n, 1u);
-        if (k < 4096) {
-            for (int t = 0; t < 6; t++) g_stamps[8 * k + t] = stamps[t];
-            g_stamps[8 * k + 6] = wave_resets ? 1 : 0;
-            g_stamps[8 * k + 7] = blockIdx.x;
-        }
-    }
+    STAMP(2);
+    stamp_log(stamps, wave_resets ? 1u : 0u);
 #endif
 }
 
@@ -1235,13 +1547,13 @@ __global__ __launch_bounds__(kWave * W) void observe_kernel(MultiParams p, float
     const float dist_t = norm32(tdx, tdy);
     const float theta = atan2_fast((float)s.vy, (float)s.vx);
     const float dth = wrap_pi(atan2_fast(tdy, tdx) - theta);
-    if (EXT && p.B > 0) stage_bodies<false>(p, m, lds, s.flags, false, true, 0u, 0u);
+    if (EXT && p.B > 0) stage_bodies<false>(p, m, lds, s.flags, false, 0u, 0u);
     if (m.active) {
         lds.pos[m.rbase + m.i] = make_float4(s.x, s.y, s.x, s.y);
         lds.theta[m.rbase + m.i] = theta;
     }
     group_sync<LDS::kW>();
-    const Neigh nb = scan_neighbours<NT, false>(w, m, lds, s.x, s.y);
+    const Neigh nb = scan_neighbours<NT, false>(w.sq_sense, m, lds, s.x, s.y);
     const float speed = __builtin_amdgcn_sqrtf((float)fma(s.vy, s.vy, s.vx * s.vx));
     float o[10];
     assemble_obs(p, w, m, lds, nb, s.x, s.y, speed, theta, dist_t, dth, o);
@@ -1270,7 +1582,7 @@ __global__ __launch_bounds__(kWave * W) void reset_kernel(MultiParams p, const u
         fold = fold_load(p, m.e);
         wc = p.wave_steps[m.wave];
     }
-    reset_envs_wave<NT, EXT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s, p.body, p.lvl_cur);
+    reset_envs_wave<NT, EXT>(p, m, lds, go, episode, (uint32_t)seed, (uint32_t)(seed >> 32), s, p.body_pos, p.body_leg, p.lvl_cur);
     if (go) {
         p.pos[m.a] = make_float2(s.x, s.y);
         p.vel[m.a] = make_double2(0.0, 0.0);
@@ -1293,11 +1605,21 @@ __global__ __launch_bounds__(kBlock) void env_levels_kernel(MultiParams p, const
     if (set_next) p.lvl_next[e] = set_next[e];
     if (get_cur) get_cur[e] = p.lvl_cur[e];
 }
-__global__ __launch_bounds__(kBlock) void bodies_kernel(MultiParams p, const float4 *set, float4 *get) {
+// public body record (include/uavx.h): UAVX_BODY_DIM = 6 floats {x, y, dx, dy, heading, legs}
+__global__ __launch_bounds__(kBlock) void bodies_kernel(MultiParams p, const float *set, float *get) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.E * p.B) return;
-    if (set) p.body[i] = set[i];
-    if (get) get[i] = p.body[i];
+    if (set) {
+        const float *r = set + i * UAVX_BODY_DIM;
+        p.body_pos[i] = make_float2(r[0], r[1]);
+        p.body_leg[i] = make_float4(r[2], r[3], r[4], r[5]);
+    }
+    if (get) {
+        const float2 q = p.body_pos[i];
+        const float4 leg = p.body_leg[i];
+        float *r = get + i * UAVX_BODY_DIM;
+        r[0] = q.x; r[1] = q.y; r[2] = leg.x; r[3] = leg.y; r[4] = leg.z; r[5] = leg.w;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void episode_stats_kernel(MultiParams p, uint32_t *counts, float *returns, int clear) {
@@ -1680,6 +2002,12 @@ extern "C" {
 
 int uavx_version(void) { return UAVX_VERSION; }
 
+#ifndef UAVX_SRC_HASH
+#define UAVX_SRC_HASH ""
+#endif
+static const char kBuildInfo[] = "UAVX_SRC_HASH=" UAVX_SRC_HASH;   // the loader finds this marker in the file without mapping it
+const char *uavx_build_info(void) { return kBuildInfo + 14; }
+
 int uavx_selftest(int device, uint64_t *mismatches) {
     if (!mismatches) return UAVX_ERR_INVALID_ARG;
     int ndev = 0;
@@ -1760,13 +2088,15 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
     const size_t o_finc = off;  off = align_up(off + E * sizeof(uint4), 256);
     const size_t o_finr = off;  off = align_up(off + E * sizeof(float2), 256);
-    const size_t o_body = off;  off = align_up(off + E * (size_t)B * sizeof(float4), 256);
+    const size_t o_bpos = off;  off = align_up(off + E * (size_t)B * sizeof(float2), 256);
+    const size_t o_bleg = off;  off = align_up(off + E * (size_t)B * sizeof(float4), 256);
     const size_t o_lcur = off;  off = align_up(off + E, 256);
     const size_t o_lnext = off; off = align_up(off + E, 256);
     const size_t o_levels = off; off = align_up(off + sizeof(LevelTable), 256);
-    const size_t o_sagent = off; off = align_up(off + A * sizeof(float4), 256);
-    const size_t o_sbody = off;  off = align_up(off + E * (size_t)B * sizeof(float4), 256);
-    const size_t o_stag = off;   off = align_up(off + E * sizeof(uint4), 256);
+    const size_t o_sagent = off; off = align_up(off + 2 * A * sizeof(float4), 256);
+    const size_t o_sbpos = off;  off = align_up(off + 2 * E * (size_t)B * sizeof(float2), 256);
+    const size_t o_sbleg = off;  off = align_up(off + 2 * E * (size_t)B * sizeof(float4), 256);
+    const size_t o_stag = off;   off = align_up(off + 2 * E * sizeof(uint4), 256);
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     e = hipMemset(h->slab, 0, off);
@@ -1782,15 +2112,18 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
     p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
     p.fin_returns = reinterpret_cast<float2 *>(b + o_finr);
-    p.body = reinterpret_cast<float4 *>(b + o_body);
+    p.body_pos = reinterpret_cast<float2 *>(b + o_bpos);
+    p.body_leg = reinterpret_cast<float4 *>(b + o_bleg);
     p.lvl_cur = reinterpret_cast<uint8_t *>(b + o_lcur);
     p.lvl_next = reinterpret_cast<uint8_t *>(b + o_lnext);
     h->levels_dev = reinterpret_cast<LevelParams *>(b + o_levels);
     p.levels = h->levels_dev;
     p.n_levels = 0; p.level_lo = -1; p.level_hi = -1;
     p.stage_agent = reinterpret_cast<float4 *>(b + o_sagent);
-    p.stage_body = reinterpret_cast<float4 *>(b + o_sbody);
+    p.stage_bpos = reinterpret_cast<float2 *>(b + o_sbpos);
+    p.stage_bleg = reinterpret_cast<float4 *>(b + o_sbleg);
     p.stage_tag = reinterpret_cast<uint4 *>(b + o_stag);   // zero-filled: no layout is valid yet
+    p.magic_s = 65536 / (N + B) + 1;
     p.world_version = 1;
     hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);  // level 0 = the config
     e = hipGetLastError();
@@ -1894,12 +2227,12 @@ int uavx_get_env_levels(uavx_handle *h, uint8_t *levels, void *stream) {
 
 static int bodies_exchange(uavx_handle *h, const float *set, float *get, void *stream) {
     if (h->p.B == 0) return fail(h, UAVX_ERR_UNSUPPORTED, "the handle has no scripted bodies");
-    if ((reinterpret_cast<uintptr_t>(set) | reinterpret_cast<uintptr_t>(get)) & 15u)
-        return fail(h, UAVX_ERR_INVALID_ARG, "body records must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(set) | reinterpret_cast<uintptr_t>(get)) & 3u)
+        return fail(h, UAVX_ERR_INVALID_ARG, "body records must be 4-byte aligned");
     UAVX_ENTER(h);
     const int64_t n = h->p.E * h->p.B;
     hipLaunchKernelGGL(bodies_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), h->p, reinterpret_cast<const float4 *>(set), reinterpret_cast<float4 *>(get));
+                       static_cast<hipStream_t>(stream), h->p, set, get);
     UAVX_HIP(h, hipGetLastError());
     return UAVX_OK;
 }
@@ -2043,9 +2376,12 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
 extern "C" int uavx_debug_stamps(unsigned long long *host_out, unsigned int *n) {  // debug builds only
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(n, HIP_SYMBOL(g_stamp_n), sizeof(unsigned int));
-    hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * 4096);
+    hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * 16384);
     unsigned int zero = 0;
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_n), &zero, sizeof zero);
+    void *dst = nullptr;
+    hipGetSymbolAddress(&dst, HIP_SYMBOL(g_stamps));
+    hipMemset(dst, 0, sizeof(unsigned long long) * 8 * 16384);
     return 0;
 }
 #endif

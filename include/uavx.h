@@ -24,11 +24,12 @@
 extern "C" {
 #endif
 
-#define UAVX_VERSION 2
+#define UAVX_VERSION 3
 #define UAVX_OBS_DIM 10     /* MUW:98-109 */
 #define UAVX_UW_OBS_DIM 4   /* UW:107-112 */
 #define UAVX_MAX_AGENTS 64  /* one wavefront holds a whole env: learners + scripted bodies <= 64 */
 #define UAVX_MAX_LEVELS 16  /* curriculum levels per handle */
+#define UAVX_BODY_DIM 6     /* floats of a scripted body's record: x, y, dx, dy, heading, legs (uavx_set_body_rule) */
 
 #define UAVX_FLAG_DONE 1u      /* AG:19 */
 #define UAVX_FLAG_COLLIDED 2u  /* AG:20 */
@@ -103,6 +104,9 @@ typedef struct uavx_handle uavx_handle;       /* E x MultiUAVWorld2D */
 typedef struct uavx_uw_handle uavx_uw_handle; /* E x UAVWorld2D */
 
 int uavx_version(void);
+/* Identity of the sources the library was built from (hash over csrc/ and this header, set by the package's build; "" for
+ * a hand-run make).  The Python loader rebuilds a library whose hash is not the one of the sources next to it. */
+const char *uavx_build_info(void);
 /* Hardware self test of the hand-written arithmetic the kernels rely on for bit-exactness: the 9-instruction
  * correctly rounded square root (csrc/uavx_device.hpp sqrt_rn) against the compiler's IEEE sqrtf on every float32
  * bit pattern.  *mismatches = number of differing results (0 expected).  Synchronous; about 10 ms. */
@@ -133,15 +137,22 @@ int uavx_set_config(uavx_handle *h, const uavx_config *cfg);
 /* ---- extension of BASELINE.json configs[4]: scripted bodies + randomized-reset curriculum (no reference counterpart) ----
  * Bodies.  The B bodies of an env are slots L .. L+B-1 of its neighbour model: they are what the learners'
  * uavs_in_range (AG:44-64), collision tests (MUW:197-210) and neighbour observation features (MUW:75-95) see, exactly
- * like further UAVs, and they are stepped AFTER the learners in the env's sequential loop (MUW:181 order: a learner's
- * collision test sees their positions of the previous step, its observation their new ones).  They read no action and
- * produce no observation / reward / done.  A body is the float32 record {x, y, wx, wy}: position and current waypoint.
- * Every env step it moves `speed*tau` metres straight towards the waypoint (onto it when closer); its heading, as seen in
- * a learner's MUW:82-85 feature, is the direction to the waypoint.  At env step s > 0 with s % period == 0 it takes a new
- * waypoint: Philox4x32-10, key = seed, counter (global env[31:0], env[47:32] | slot << 16, 0x80000000 | s / period,
- * episode), words 0,1 uniform over the env's box (float32).  reset draws the bodies' start points after the learners' in
- * slot order under the same > 2R rejection rule (MUW:127-137) and waypoint 0.  period must be a power of two.
- * Defaults: speed 5 m/s, period 128, seed 0.  Host-only call: later launches see the new rule. */
+ * like further UAVs, and they are stepped BEFORE the learners of the env's sequential loop (the world's scripted traffic
+ * advances, then the UAVs move in MUW:181 order): a learner's collision test and its observation see the same, new, body
+ * positions.  They read no action and produce no observation / reward / done.
+ * A body travels in LEGS.  Its record is six float32 {x, y, dx, dy, heading, legs}: position, displacement per env step,
+ * direction of travel (what a learner's MUW:82-85 feature shows) and the number of steps of the leg during which it moves.
+ * A leg starts at reset (leg 0) and at every env step s > 0 with s % period == 0 (leg s / period): the body takes waypoint
+ * W = Philox4x32-10, key = seed, counter (global env[31:0], env[47:32] | slot << 16, 0x80000000 | leg, episode), words 0,1
+ * uniform over the env's box (float32), and from its position P (float32 arithmetic, no FMA):
+ *     d = ||W - P||,  (dx, dy) = (W - P) * (speed*tau / d),  legs = floor(d / (speed*tau)),  heading = atan2(W - P)
+ * (d == 0: no displacement, no legs).  In env step s it moves (x += dx, y += dy) iff s % period < legs: straight towards the
+ * waypoint at `speed` m/s, stopping less than one step short of it until the next leg starts.  Between two waypoints the
+ * kernel therefore reads 24 B and writes 8 B per body-step and spends two additions on it (round 2 kept {x, y, wx, wy} and
+ * paid a norm, a division and an atan2 per body-step: 130 of the 1100 vector instructions of a wavefront).
+ * reset draws the bodies' start points after the learners' in slot order under the same > 2R rejection rule (MUW:127-137).
+ * period must be a power of two.  Defaults: speed 5 m/s, period 128, seed 0.  Host-only call: later launches see the new
+ * rule (a running leg keeps the displacement it was started with). */
 typedef struct {
     double speed;
     int32_t period;
@@ -150,7 +161,7 @@ typedef struct {
 } uavx_body_rule;
 int uavx_set_body_rule(uavx_handle *h, const uavx_body_rule *rule);
 int uavx_num_bodies(const uavx_handle *h);
-/* Body records [E*B*4] float32 {x, y, wx, wy}, device pointers. */
+/* Body records [E*B*UAVX_BODY_DIM] float32 {x, y, dx, dy, heading, legs}, device pointers. */
 int uavx_get_bodies(uavx_handle *h, float *records, void *stream);
 int uavx_set_bodies(uavx_handle *h, const float *records, void *stream);
 
@@ -242,15 +253,17 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
 
 /* Layouts drawn ahead of time (default: every = 16).  The start / target layout of an env's next episode depends only on
  * (seed, global env id, episode index, level rule), so every uavx_step_ex launch with an auto-reset policy or a step cap
- * carries ceil(G / every) extra workgroups in front of its G env-workgroups: they step nothing, they look after one slice
- * of the envs (the slice rotates with the handle's step count, a device-side counter: replays of a captured graph rotate
- * like eager calls) and draw the layouts of the episodes that will start next into a staging area.  A step workgroup then
- * re-initialises an env with 16-byte copies instead of running the serial accept / reject chain of MUW:127-153 on one
- * wavefront while the rest of the chip waits for it; the chains of the staging workgroups start first and finish
- * underneath the same launch (profiles/r02_ab_notes.md).  A layout parked for another seed / world / level, or a second
- * episode end of the same env within `every` launches, simply misses and is drawn in the step workgroup as before:
- * results are identical either way.  every = 0 switches staging off; every = 1 looks after every env in every launch.
- * No second kernel, stream or event is involved: one launch per call, on `stream`. */
+ * carries ceil(G / every) extra workgroups in front of its G env-workgroups.  They step nothing: each looks at one window of
+ * envs (a lane per env; every window comes round every few launches), finds the envs whose parked layouts -- an env keeps
+ * TWO, for its next episode and the one after -- are missing, consumed or drawn for another seed / world / level, and draws
+ * the first few of them into a staging area, one lane per slot of the neighbour model.  A step workgroup then re-initialises
+ * an env with 16-byte copies instead of running the serial accept / reject chain of MUW:127-153 on one wavefront while the
+ * rest of the chip waits for it (with 16 scripted bodies that chain is 8-19 us on its own; profiles/r03_ab_notes.md).  A
+ * layout that is not there when it is needed -- first use, a new seed / world / curriculum window (all parked layouts are
+ * then worked off again at ceil(G / every) * floor(64 / slots) per launch), two episode ends of one env within a few
+ * launches -- is drawn in the step workgroup as before: results are identical either way.  every = 0 switches staging off.
+ * No second kernel, stream or event is involved: one launch per call, on `stream`; a captured graph behaves like eager calls
+ * (nothing on the host counts launches). */
 int uavx_set_prefetch(uavx_handle *h, int every);
 
 /* Per-env statistics over the episodes ended so far (by auto-reset or uavx_reset):

@@ -197,7 +197,7 @@ class OracleMulti:
         self.fin_returns = np.zeros((E, 2), np.float32)
         self._ep = _EpisodeState(_p(self.pending), _p(self.ep_run), _p(self.fin_counts), _p(self.fin_returns))
         # configs[4] extension (scripted bodies, curriculum levels); inert when B == 0 and no levels are installed
-        self.body = np.zeros((E, max(self.B, 1), 4), np.float32)[:, :self.B]
+        self.body = np.zeros((E, max(self.B, 1), 6), np.float32)[:, :self.B]   # x, y, dx, dy, heading, legs
         self.body = np.ascontiguousarray(self.body)
         self.level = np.zeros((E,), np.uint8)
         self.next_level = np.zeros((E,), np.uint8)

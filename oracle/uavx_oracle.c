@@ -167,7 +167,7 @@ typedef struct {
     int L;               /* learner slots (st->num_agents) */
     int nl;              /* learners taking part (level.n_active) */
     int B, nb;           /* body slots / bodies taking part */
-    float *body;         /* [B*4] x, y, wx, wy of this env, or NULL */
+    float *body;         /* [B*6] x, y, dx, dy, heading, legs of this env (uavx.h, uavx_set_body_rule), or NULL */
     float body_step;     /* float32(body_speed * tau): distance a body covers per env step */
     int period;
     uint32_t key[2], env_ctr[2];
@@ -180,7 +180,7 @@ static void make_envx(const uavo_config *cfg, const uavo_ext *ext, const uavo_ex
     x->L = x->nl = st->num_agents;
     if (!ext || !xs) return;
     x->B = x->nb = ext->num_bodies;
-    x->body = (ext->num_bodies > 0) ? xs->body + (size_t)e * ext->num_bodies * 4 : NULL;
+    x->body = (ext->num_bodies > 0) ? xs->body + (size_t)e * ext->num_bodies * UAVO_BODY_DIM : NULL;
     x->body_step = (float)(ext->body_speed * cfg->tau);
     x->period = ext->body_period > 0 ? ext->body_period : 1;
     x->key[0] = (uint32_t)ext->body_seed; x->key[1] = (uint32_t)(ext->body_seed >> 32);
@@ -207,21 +207,55 @@ static void body_waypoint(const envx *x, int b, uint32_t leg, uint32_t ep_draw, 
     wp[1] = (float)(loy + sy * ((double)o[1] * (1.0 / 4294967296.0)));
 }
 
-/* One env step of body b (all float32, no FMA): re-target at the start of every `period`-th step, then move
- * body_step metres straight towards the waypoint (or onto it when it is closer than that). */
-static void body_move(const envx *x, int b, uint32_t steps_before, uint32_t ep_draw) {
-    float *r = x->body + 4 * b;
-    if (steps_before != 0 && steps_before % (uint32_t)x->period == 0)
-        body_waypoint(x, b, steps_before / (uint32_t)x->period, ep_draw, r + 2);
-    const float dx = r[2] - r[0], dy = r[3] - r[1];
+/* atan2f for the heading of a leg: the device's octant reduction + Cephes polynomial (csrc/uavx_device.hpp,
+ * atan2_exact) with an IEEE division, every operation correctly rounded and in the same order, so that the stored
+ * heading is the same float32 on both sides. */
+static float atan2_leg(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const int big = mn > 0.41421356237f * mx;
+    const float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    den = (mx == 0.f) ? 1.f : den;
+    const float t = num / den;
+    const float z = t * t;
+    float pl = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    pl = fmaf(pl, z, 1.99777106478e-1f);
+    pl = fmaf(pl, z, -3.33329491539e-1f);
+    float r = fmaf(pl * z, t, t);
+    r = big ? r + 0.78539816339744830962f : r;
+    r = (ay > ax) ? 1.57079632679489661923f - r : r;
+    r = (x < 0.f) ? 3.14159265358979323846f - r : r;
+    return copysignf(r, y);
+}
+
+/* A body starts a leg at its position (r[0], r[1]) towards waypoint wp (all float32, no FMA): displacement per env
+ * step = (wp - P) * (body_step / ||wp - P||), heading = direction of travel, legs = number of whole steps that fit
+ * into the distance (the body stops less than one step short of the waypoint and waits there for the next leg). */
+static void body_leg(const envx *x, float *r, const float wp[2]) {
+    const float dx = wp[0] - r[0], dy = wp[1] - r[1];
     const float d = nrm32(dx, dy);
-    if (d > x->body_step) {
+    if (d > 0.f) {
         const float sc = x->body_step / d;
-        const float mx = dx * sc, my = dy * sc;
-        r[0] = r[0] + mx; r[1] = r[1] + my;
+        r[2] = dx * sc; r[3] = dy * sc;
+        r[5] = floorf(d / x->body_step);       /* body_step == 0 (static obstacle): +inf legs of zero displacement */
     } else {
-        r[0] = r[2]; r[1] = r[3];
+        r[2] = r[3] = 0.f; r[5] = 0.f;
     }
+    r[4] = atan2_leg(dy, dx);
+}
+
+/* One env step of body b: at the start of every `period`-th step it takes a new waypoint and starts a leg from
+ * where it is; it then moves by its displacement while the leg still has whole steps left. */
+static void body_move(const envx *x, int b, uint32_t steps_before, uint32_t ep_draw) {
+    float *r = x->body + UAVO_BODY_DIM * b;
+    const uint32_t k = steps_before % (uint32_t)x->period;
+    if (steps_before != 0 && k == 0) {
+        float wp[2];
+        body_waypoint(x, b, steps_before / (uint32_t)x->period, ep_draw, wp);
+        body_leg(x, r, wp);
+    }
+    if ((float)k < r[5]) { r[0] = r[0] + r[2]; r[1] = r[1] + r[3]; }
 }
 
 /* positions (and, for the observation, velocities) of every slot of the neighbour model: learners 0..L-1 then
@@ -234,9 +268,9 @@ static int gather_slots(const envx *x, const double *loc, const double *vel, dou
     }
     for (int b = 0; b < x->B; b++) {
         const int j = x->L + b, on = b < x->nb;
-        const float *r = x->body + 4 * b;
+        const float *r = x->body + UAVO_BODY_DIM * b;
         px[j] = on ? (double)r[0] : INFINITY; py[j] = on ? (double)r[1] : INFINITY;
-        if (vx) { vx[j] = (double)(r[2] - r[0]); vy[j] = (double)(r[3] - r[1]); }  /* heading of a body: towards its waypoint */
+        if (vx) { vx[j] = cos((double)r[4]); vy[j] = sin((double)r[4]); }  /* a body's heading is the stored float32 angle */
     }
     return x->L + x->B;
 }
@@ -359,8 +393,8 @@ static void reset_env(const envx *x, uavo_state *st, int64_t e, draw_src *src, i
         }
     }
     for (int b = 0; b < x->B; b++) {                                   /* extension: body start points */
-        float *r = x->body + 4 * b;
-        if (b >= x->nb) { r[0] = r[1] = INFINITY; r[2] = r[3] = 0.f; continue; }
+        float *r = x->body + UAVO_BODY_DIM * b;
+        if (b >= x->nb) { r[0] = r[1] = INFINITY; r[2] = r[3] = r[4] = r[5] = 0.f; continue; }
         int replicated = 1;
         double q[2];
         draw_begin(src, (uint32_t)(x->L + b), 0);
@@ -370,10 +404,12 @@ static void reset_env(const envx *x, uavo_state *st, int64_t e, draw_src *src, i
             for (int j = 0; j < nl && !replicated; j++)
                 if ((float)pos_dist(0, loc[2 * j], loc[2 * j + 1], q[0], q[1]) <= two_r) replicated = 1;
             for (int j = 0; j < b && !replicated; j++)
-                if ((float)pos_dist(0, (double)x->body[4 * j], (double)x->body[4 * j + 1], q[0], q[1]) <= two_r) replicated = 1;
+                if ((float)pos_dist(0, (double)x->body[UAVO_BODY_DIM * j], (double)x->body[UAVO_BODY_DIM * j + 1], q[0], q[1]) <= two_r) replicated = 1;
         }
         r[0] = (float)q[0]; r[1] = (float)q[1];
-        body_waypoint(x, b, 0u, src->episode & 0x7FFFFFFFu, r + 2);
+        float wp[2];
+        body_waypoint(x, b, 0u, src->episode & 0x7FFFFFFFu, wp);
+        body_leg(x, r, wp);
     }
     for (int i = 0; i < nl; i++) {                                     /* MUW:140-155 */
         int replicated = 1;
@@ -487,7 +523,10 @@ static void step_env(const envx *x, uavo_state *st, int64_t e, const double *act
     const double lox = -cfg->x_size / 2.0, loy = -cfg->y_size / 2.0;
     const double hix = cfg->x_size / 2.0, hiy = cfg->y_size / 2.0;
     double px[MAXN], py[MAXN];
-    const int ntot = gather_slots(x, loc, vel, px, py, NULL, NULL);  /* bodies (extension) move after the learners */
+    /* extension: the scripted bodies move FIRST (the world's traffic advances, then the UAVs move in MUW:181 order), so a
+     * learner's collision test and its observation see the same -- new -- body positions */
+    for (int b = 0; b < x->nb; b++) body_move(x, b, cnt[0], (cnt[3] - 1u) & 0x7FFFFFFFu);
+    const int ntot = gather_slots(x, loc, vel, px, py, NULL, NULL);
 
     for (int i = 0; i < n; i++) {                                       /* MUW:181 */
         const double *a = actions + (e * n + i) * 2;
@@ -568,7 +607,6 @@ static void step_env(const envx *x, uavo_state *st, int64_t e, const double *act
         reward[e * n + i] = r;
         done_out[e * n + i] = (uint8_t)dn;
     }
-    for (int b = 0; b < x->nb; b++) body_move(x, b, cnt[0], (cnt[3] - 1u) & 0x7FFFFFFFu);  /* extension */
     observe_env(x, st, e, obs);                                                      /* MUW:233-235 */
     cnt[0] += 1;                                                                     /* MUW:238 */
 }

@@ -109,13 +109,14 @@ void uavo_fold_episode(uavo_state *st, uavo_episode_state *ep, int64_t env);
 /* ---- world extension of BASELINE.json configs[4] (NO reference counterpart: "parity unpinned" by the reference;
  * these functions restate the build's own definition in include/uavx.h so the HIP path can be checked bit for bit) ----
  *  - scripted bodies: B non-learning records per env that sit in the neighbour model as agents L .. L+B-1 (they are
- *    what uavs_in_range / the collision tests of the L learners see, AG:44-64, MUW:197-210), stepped AFTER the learners
- *    in the env's sequential loop (MUW:181 order) by a waypoint rule keyed by Philox;
+ *    what uavs_in_range / the collision tests of the L learners see, AG:44-64, MUW:197-210), stepped BEFORE the learners
+ *    of the env's sequential loop (MUW:181) by a waypoint rule keyed by Philox: legs of constant displacement per step;
  *  - curriculum levels: per-env box size / d_sense / collider radius / number of active learners and bodies, chosen
  *    when the env is reset (randomized-reset curriculum);
  *  - step_ex reports which envs ended at this call and which of those were cut by the step cap (truncated). */
 #define UAVO_FLAG_INACTIVE 32u /* learner parked by its level's n_active: not stepped, never a neighbour */
 #define UAVO_MAX_LEVELS 16
+#define UAVO_BODY_DIM 6
 typedef struct {
     double x_size, y_size, collider_radius, d_sense;
     int32_t n_active;   /* learners 0 .. n_active-1 take part (1 .. L) */
@@ -134,7 +135,7 @@ typedef struct {
 } uavo_ext;
 
 typedef struct {
-    float *body;         /* [E*B*4] x, y, waypoint x, waypoint y (float32) */
+    float *body;         /* [E*B*6] x, y, displacement per step x, y, heading, steps of the leg that move (float32) */
     uint8_t *level;      /* [E] level in force since the env's last reset */
     uint8_t *next_level; /* [E] level an explicit assignment asked for (used when level_lo < 0) */
 } uavo_ext_state;

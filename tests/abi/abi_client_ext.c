@@ -1,4 +1,4 @@
-/* Native client of the ABI-version-2 entry points (include/uavx.h): scripted bodies, curriculum levels, the fused
+/* Native client of the ABI entry points added in versions 2 and 3 (include/uavx.h): scripted bodies, curriculum levels, the fused
  * uavx_step_ex with its ended / truncated outputs -- plain C, no Python, no torch; the checker is the oracle's C library
  * (uavo_*_x).  The extension has no reference counterpart (see uavx.h); what is compared is the HIP path against the
  * oracle's restatement of the same definition: reset / done / ended / truncated masks, levels, body records, learner
@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipMalloc((void **)&d_done, A));
     CHECK_HIP(hipMalloc((void **)&d_loc, A * 2 * sizeof(float)));
     CHECK_HIP(hipMalloc((void **)&d_aflags, A));
-    CHECK_HIP(hipMalloc((void **)&d_body, (size_t)E * (B ? B : 1) * 4 * sizeof(float)));
+    CHECK_HIP(hipMalloc((void **)&d_body, (size_t)E * (B ? B : 1) * UAVX_BODY_DIM * sizeof(float)));
     CHECK_HIP(hipMalloc((void **)&d_flags3, 3 * E));
     CHECK_HIP(hipMalloc((void **)&d_lvl, E));
     CHECK_HIP(hipMalloc((void **)&d_cnt, E * 4 * sizeof(uint32_t)));
@@ -84,12 +84,12 @@ int main(int argc, char **argv) {
     st.loc = calloc(A * 2, sizeof(double)); st.vel = calloc(A * 2, sizeof(double)); st.tgt = calloc(A * 2, sizeof(double));
     st.init_d = calloc(A, sizeof(double)); st.prev_d = calloc(A, sizeof(double)); st.flags = calloc(A, 1);
     st.counters = calloc(E * 4, sizeof(uint32_t)); st.f64pos = calloc(E, 1);
-    uavo_ext_state xs = {calloc((size_t)E * (B ? B : 1) * 4, sizeof(float)), calloc(E, 1), calloc(E, 1)};
+    uavo_ext_state xs = {calloc((size_t)E * (B ? B : 1) * UAVO_BODY_DIM, sizeof(float)), calloc(E, 1), calloc(E, 1)};
     uavo_episode_state ep = {calloc(E, 1), calloc(E * 2, sizeof(float)), calloc(E * 4, sizeof(uint32_t)), calloc(E * 2, sizeof(float))};
     double *o_act = malloc(A * 2 * sizeof(double)), *o_obs = malloc(A * UAVO_OBS_DIM * sizeof(double)), *o_rew = malloc(A * sizeof(double));
     uint8_t *o_done = malloc(A), *o_rm = malloc(E), *o_en = malloc(E), *o_tr = malloc(E);
     float *h_act = malloc(A * 2 * sizeof(float)), *g_obs = malloc(A * UAVO_OBS_DIM * sizeof(float)), *g_rew = malloc(A * sizeof(float));
-    float *g_loc = malloc(A * 2 * sizeof(float)), *g_body = malloc((size_t)E * (B ? B : 1) * 4 * sizeof(float));
+    float *g_loc = malloc(A * 2 * sizeof(float)), *g_body = malloc((size_t)E * (B ? B : 1) * UAVX_BODY_DIM * sizeof(float));
     uint8_t *g_done = malloc(A), *g_flags3 = malloc(3 * E), *g_lvl = malloc(E), *g_aflags = malloc(A);
     uint32_t *g_cnt = malloc(E * 4 * sizeof(uint32_t));
 
@@ -122,7 +122,7 @@ int main(int argc, char **argv) {
         CHECK_HIP(hipMemcpyAsync(g_aflags, d_aflags, A, hipMemcpyDeviceToHost, stream));
         CHECK_HIP(hipMemcpyAsync(g_cnt, d_cnt, E * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         CHECK_HIP(hipMemcpyAsync(g_lvl, d_lvl, E, hipMemcpyDeviceToHost, stream));
-        if (B) CHECK_HIP(hipMemcpyAsync(g_body, d_body, (size_t)E * B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (B) CHECK_HIP(hipMemcpyAsync(g_body, d_body, (size_t)E * B * UAVX_BODY_DIM * sizeof(float), hipMemcpyDeviceToHost, stream));
         uavo_step_ex_x(&ocfg, &ext, &st, &xs, &ep, &opt, o_act, 1, o_obs, o_rew, o_done, o_rm, o_en, o_tr, 4);
         CHECK_HIP(hipStreamSynchronize(stream));
         for (int64_t e = 0; e < E; e++) {
@@ -137,7 +137,7 @@ int main(int argc, char **argv) {
             const double dr = fabs((double)g_rew[a] - o_rew[a]) / fmax(1.0, fabs(o_rew[a]));
             if (dr > worst_rew) worst_rew = dr;
         }
-        for (int64_t k = 0; k < (int64_t)E * B * 4; k++) bad += memcmp(&g_body[k], &xs.body[k], 4) != 0;
+        for (int64_t k = 0; k < (int64_t)E * B * UAVX_BODY_DIM; k++) bad += memcmp(&g_body[k], &xs.body[k], 4) != 0;
         for (int64_t k = 0; k < A * UAVO_OBS_DIM; k++) {
             const double d = angle_col[k % UAVO_OBS_DIM] ? circ_diff(g_obs[k], o_obs[k]) : fabs(g_obs[k] - o_obs[k]);
             if (d > worst_obs) worst_obs = d;

@@ -144,6 +144,46 @@ def test_config5_combined_vs_oracle(amd, oracle_mod, prefetch):
     env.close()
 
 
+@pytest.mark.parametrize("cap,L,B", [(1, 8, 16), (2, 8, 16), (2, 3, 5), (1, 4, 0)])
+def test_staging_overlaps_the_reset_it_serves(amd, oracle_mod, cap, L, B):
+    """Episodes of one and two steps with staging workgroups in EVERY launch (prefetch every = 1): each launch re-initialises
+    half (or a third) of the envs from the parked layouts while staging workgroups of the same launch scan, and redraw, the
+    layouts of those very envs.  What keeps that correct is written down at stage_ahead (csrc/uavx_multi.hip): the slot a
+    re-initialising env reads is left alone while its "ended" mark stands, and the mark is cleared by the env's last store,
+    after every load from the staging arrays has returned.  Every output and the whole state against the oracle, every step;
+    a seed change in the middle invalidates everything that is parked."""
+    import torch
+    E = 4096
+    kw = dict(num_agents=L, num_bodies=B, body_period=4, x_size=26.0, y_size=22.0, d_sense=9.0, collider_radius=0.6)
+    levels = [dict(x_size=20.0, y_size=18.0, collider_radius=0.5, d_sense=8.0, n_active=max(1, L // 2), b_active=B // 2),
+              dict(x_size=26.0, y_size=22.0, collider_radius=0.6, d_sense=9.0, n_active=L, b_active=B)]
+    env = amd.BatchedMultiUAVWorld2D(E, seed=31, env_offset=11, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.set_prefetch(1)
+    env.set_curriculum(levels, lo=0, hi=1); orc.set_curriculum(levels, lo=0, hi=1)
+    env.reset(); orc.reset_philox(31, env_offset=11)
+    rng = np.random.default_rng(cap * 100 + L)
+    seed, hits = 31, 0
+    for t in range(60):
+        if t == 37:
+            seed = 32
+            env.seed = seed
+        a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
+        obs_g, rew_g, done_g, info = env.step_ex(torch.from_numpy(a).to(env.device), polar=True, auto_reset="agent0_done", step_cap=cap)
+        obs_o, rew_o, done_o, rm_o, en_o, tr_o = orc.step_ex(a, action_mode=1, reset_policy=1, step_cap=cap, seed=seed, env_offset=11,
+                                                             with_end=True)
+        ctx = f"cap {cap}, step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(info["ended"]).astype(np.uint8), en_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(env.env_levels()), orc.level, err_msg=ctx)
+        _compare_state(env, orc, ctx)
+        assert obs_err(_np(obs_g), obs_o) <= TOL and float(np.abs(_np(rew_g) - rew_o).max()) <= TOL, ctx
+        hits += int(rm_o.sum())
+    assert hits >= E * 60 // (cap + 1) - E
+    env.close()
+
+
 def test_explicit_env_levels_and_parked_learners(amd, oracle_mod):
     """No bodies; levels assigned per env by the caller; parked learners report obs 0 / reward 0 / done 1 and are nobody's
     neighbour; a one-level curriculum equal to the config reproduces the plain kernels bit for bit."""

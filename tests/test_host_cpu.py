@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.uavx_version() == 2
+    assert lib.uavx_version() == 3
     assert lib.uavx_strerror(-1) == b"invalid argument"
 
 
@@ -214,6 +214,8 @@ def test_lane_to_env_multiply_shift_is_exact():
     for n in range(1, 65):
         magic = 65536 // n + 1
         assert all(((lane * magic) >> 16) == lane // n for lane in range(64)), n
+        # staging workgroups map a lane per SLOT with the same trick over up to four wavefronts (stage_ahead, magic_s)
+        assert all(((lane * magic) >> 16) == lane // n for lane in range(256)), n
 
 
 def test_checkpoint_written_in_the_reference_layout(tmp_path):

@@ -67,9 +67,16 @@ def test_extension_invariants(oracle_mod):
             lv = levels[o.level[e]]
             on = o.body[e, :lv["b_active"]]
             assert (np.abs(on[:, 0]) <= lv["x_size"] / 2 + 1e-4).all() and (np.abs(on[:, 1]) <= lv["y_size"] / 2 + 1e-4).all()
-            if not rm[e]:   # a body covers at most speed * tau per step
+            if not rm[e]:   # a body covers speed * tau per step while its leg lasts, and rests afterwards
                 mv = np.linalg.norm(on[:, :2] - prev[e, :lv["b_active"], :2], axis=-1)
                 assert (mv <= 4.0 * 0.02 + 1e-5).all()
+                assert (np.isclose(mv, 4.0 * 0.02, atol=1e-5) | (mv == 0)).all()
+            # the record: displacement of length speed * tau (or 0), heading = its direction, a whole number of moving steps
+            dlen = np.linalg.norm(on[:, 2:4].astype(np.float64), axis=-1)
+            assert (np.isclose(dlen, 4.0 * 0.02, atol=1e-6) | (dlen == 0)).all()
+            mvg = dlen > 0
+            assert np.allclose(on[mvg, 4], np.arctan2(on[mvg, 3].astype(np.float64), on[mvg, 2].astype(np.float64)), atol=2e-5)   # (float32 direction of a 0.08 m vector)
+            assert (on[:, 5] == np.floor(on[:, 5])).all() and (on[:, 5] >= 0).all()
         prev = o.body.copy()
     # determinism and independence of the shard cut (Philox keyed by global env id), bodies and levels included
     whole = mk(); whole.set_curriculum(levels, lo=0, hi=1); whole.reset_philox(3)
