@@ -369,6 +369,9 @@ __device__ __forceinline__ Neigh scan_neighbours_exact(float sq_sense, const Lan
 // is one of the fallback conditions.  Bit-identical to scan_neighbours_exact.  A slot that does not take part
 // (parked learner, inactive body: extension) is staged at +inf: its key sorts above every real one and its
 // squared distance fails every threshold.
+#ifdef UAVX_STAMPS
+__shared__ int g_dbg_fallback;   // diagnostic build: this workgroup took the exact scan / the finish() branch (bits 0 / 1)
+#endif
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -455,8 +458,10 @@ __device__ __forceinline__ Neigh scan_neighbours(float sq_sense, const LaneMap &
     }
     // N > 5: at least five neighbours were visited, so k1..k3 are real keys
     const uint32_t t1 = k1 >> 6, t2 = k2 >> 6, t3 = k3 >> 6, ts = __float_as_uint(sq_sense) >> 6;
-    const bool near_tie = (t2 - t1 <= 1u && t1 <= ts) || (t3 - t2 <= 1u && t2 <= ts);
-    if (__any(near_tie)) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);
+    const bool near_tie = m.active && ((t2 - t1 <= 1u && t1 <= ts) || (t3 - t2 <= 1u && t2 <= ts));
+#ifdef UAVX_STAMPS
+    if (__any(near_tie)) g_dbg_fallback = 1;
+#endif
     const int c1 = (int)(k1 & 63u), c2 = (int)(k2 & 63u);
     const int j1 = c1 + (c1 >= m.i ? 1 : 0), j2 = c2 + (c2 >= m.i ? 1 : 0);
     const float4 q1 = row[j1], q2 = row[j2];
@@ -470,6 +475,49 @@ __device__ __forceinline__ Neigh scan_neighbours(float sq_sense, const LaneMap &
     r.d2 = in2 ? sqrt_rn(s2) : INFINITY;
     r.j1 = in1 ? j1 : -1;
     r.j2 = in2 ? j2 : -1;
+    // Near ties (about one wavefront in 800 on random layouts; every wavefront of a symmetric one): the two nearest of a TIED
+    // LANE are found again, exactly, by the whole wavefront -- lane t takes the tied agent's t-th neighbour, float32 distance
+    // with the IEEE root, and two 64-bit minimum reductions over (distance bits, slot) give the reference's order (AG:52-62:
+    // ascending distance, ties -> lower index).  About 150 instructions per tied lane.  Round 2 sent the whole wavefront
+    // through the compare / select scan instead (+700 instructions, +43 % on the wavefront's life): with ~10 such wavefronts
+    // in every 65 536-env launch those were the ones each launch ended with (tools/exp_stamps.py).  The minimum for the
+    // collision tests (step_sq_min) is exact on the key path as it is.
+    unsigned long long tied = __ballot(near_tie);
+    if (__popcll(tied) > 6) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);   // a symmetric layout: everybody ties
+    while (tied != 0ull) {   // wave-uniform
+        const int tl = (int)__builtin_ctzll(tied);
+        tied &= tied - 1ull;
+        const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nx), tl));
+        const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ny), tl));
+        const float lim = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sq_sense), tl));
+        const int ti = __builtin_amdgcn_readlane(m.i, tl), trb = __builtin_amdgcn_readlane(m.rbase, tl);
+        const int t = (int)(threadIdx.x & (kWave - 1));
+        const bool mine = t < N - 1;
+        const int j = mine ? t + (t >= ti ? 1 : 0) : ti;                     // idle lanes look at the agent itself (distance 0, masked out)
+        const float4 q = lds.pos[trb + j];
+        const float dx = q.z - ax, dy = q.w - ay;
+        const float xx = dx * dx, yy = dy * dy;
+        const float sn = xx + yy;
+        const float dn = sqrt_rn(sn);                                       // (wave-uniform inside: every lane calls it)
+        unsigned long long key = (mine && sn < lim) ? ((unsigned long long)__float_as_uint(dn) << 32) | (uint32_t)j : ~0ull;   // AG:52
+        auto wave_min = [](unsigned long long k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t hi = __shfl_xor((uint32_t)(k >> 32), off), lo = __shfl_xor((uint32_t)k, off);
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                k = o < k ? o : k;
+            }
+            return k;
+        };
+        const unsigned long long m1 = wave_min(key);
+        const unsigned long long m2 = wave_min(key == m1 ? ~0ull : key);
+        if (t == tl) {
+            r.d1 = m1 == ~0ull ? INFINITY : __uint_as_float((uint32_t)(m1 >> 32));
+            r.j1 = m1 == ~0ull ? -1 : (int)(uint32_t)m1;
+            r.d2 = m2 == ~0ull ? INFINITY : __uint_as_float((uint32_t)(m2 >> 32));
+            r.j2 = m2 == ~0ull ? -1 : (int)(uint32_t)m2;
+        }
+    }
     return r;
 }
 
@@ -1306,6 +1354,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
+    g_dbg_fallback = 0;
 #endif
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
@@ -1488,7 +1537,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
     }
 #ifdef UAVX_STAMPS
     STAMP(2);
-    stamp_log(stamps, wave_resets ? 1u : 0u);
+    stamp_log(stamps, (wave_resets ? 1u : 0u) | (g_dbg_fallback ? 4u : 0u));
 #endif
 }
 

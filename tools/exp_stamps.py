@@ -24,7 +24,7 @@ kw = dict(polar=True, track_returns=True, auto_reset="agent0_done", step_cap=150
 for k in range(400):
     env.step_ex(ring[k % R], **kw)
 L.uavx_debug_stamps(buf, ctypes.byref(n))
-names = {0: "step", 1: "step+reinit", 10: "scan, nothing", 11: "scan, appended", 12: "queued ids needed nothing", 13: "drew layouts"}
+names = {0: "step", 1: "step+reinit", 4: "step, exact scan", 5: "step+reinit, exact scan", 10: "scan, nothing", 11: "scan, appended", 12: "queued ids needed nothing", 13: "drew layouts"}
 for rep in range(3):
     for k in range(3):
         env.step_ex(ring[k % R], **kw)
@@ -54,11 +54,14 @@ for rep in range(3):
         d = end[s] - start[s]
         print(f"  {names.get(kd, kd):26s} n={s.sum():5d}  start med {int(np.median(start[s])):6d} max {start[s].max():6d} | life med {int(np.median(d)):6d} "
               f"p99 {int(np.percentile(d, 99)):6d} max {d.max():6d} | end med {int(np.median(end[s])):6d} p99 {int(np.percentile(end[s], 99)):6d} max {end[s].max():6d}")
-    sw = kind <= 1
+    sw = kind <= 5
     for x in np.unique(xcc):
         q = sw & (xcc == x)
         lt = np.sort(start[q])
         print(f"    xcd {x}: step waves {q.sum()}, starts p50 {int(lt[len(lt) // 2])} p90 {int(lt[int(len(lt) * .9)])} p99 {int(lt[int(len(lt) * .99)])} max {lt[-1]}, "
               f"life of the first half {int(np.median((end - start)[q & (start <= lt[len(lt) // 2])]))}, of the last tenth {int(np.median((end - start)[q & (start >= lt[int(len(lt) * .9)])]))}, last end {end[q].max()}")
+    life = end - start
+    slow = np.argsort(np.where(sw, life, 0))[-12:]
+    print("  longest-lived step waves (block, life, mid-start, end-mid):", [(int(blk[i]), int(life[i]), int(mid[i] - start[i]), int(end[i] - mid[i])) for i in slow])
     last = np.argsort(end)[-8:]
     print("  last to end:", [(names.get(int(kind[i]), int(kind[i])), int(blk[i]), int(start[i]), int(end[i])) for i in last])
