@@ -366,6 +366,9 @@ def main():
     ap.add_argument("--replay", action="store_true",
                     help="with --fused: obs / reward / done / episode flags land zero-copy in a DeviceReplay ring of --ring slots "
                          "and the commands are read from its action slots")
+    ap.add_argument("--packed-flags", action="store_true",
+                    help="with --fused: UAVX_FLAGS_IN_DONE (ABI v3): reset_mask / ended / truncated ride in bits 1..3 of every env's "
+                         "first done byte instead of three one-byte-per-env arrays")
     ap.add_argument("--cfg5", action="store_true",
                     help="BASELINE configs[4] as designed: --agents 8 --bodies 16 --fused --curriculum 4 --replay")
     ap.add_argument("--mode", choices=("graph", "launch"), default="graph",
@@ -452,11 +455,11 @@ def main():
             if args.replay:
                 # slot k of the ring holds the command, reward, done and flags of step k and the observation step k - 1
                 # produced: the launch reads replay.act[k] and writes obs -> slot k + 1, the rest -> slot k (nothing is copied)
-                replay = DeviceReplay(env, horizon=args.ring - 1, num_learners=N)
+                replay = DeviceReplay(env, horizon=args.ring - 1, num_learners=N, packed_flags=args.packed_flags)
                 replay.act.copy_(ring)
                 step = lambda a: replay.step(None, **fused_kw)
             else:
-                step = lambda a: env.step_ex(a, **fused_kw)
+                step = lambda a: env.step_ex(a, packed_flags=args.packed_flags, **fused_kw)
             kernel_name = f"uavx::step_ex_kernel<{0 if ext else nt(N)}"
         else:
             ring = polar_actions(gen, (args.ring, E, N), float(np.sqrt(200.0)), device)
@@ -505,7 +508,7 @@ def main():
             summ["ended_episodes"] = env.evaluation_summary()
         slots = N + B
         shape = (f"{E}x{N}" + (f"+{B}" if B else "") + ("f" if args.fused else "")   # the tag tools/profile_round.sh files it under
-                 + (f"c{args.curriculum}" if args.curriculum else "") + ("r" if args.replay else ""))
+                 + (f"c{args.curriculum}" if args.curriculum else "") + ("r" if args.replay else "") + ("p" if args.packed_flags else ""))
         traffic = measured_traffic(kernel_name, shape) if args.world == "multi" else None
         ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
         if args.replay:   # every slot of the ring has its own obs / reward / done / flag rows
@@ -535,6 +538,7 @@ def main():
             "config": {"workload": f"{E} envs x {N} UAVs" + (f" + {B} scripted bodies" if B else "") + f" per GPU ({cfg_tag}), "
                                    f"{world_name} defaults, polar U(-1,1)^2 actions from a {args.ring}-batch HBM ring, mode={mode}"
                                    + (", fused step_ex (polar conversion + auto-reset + episode stats)" if args.fused else "")
+                                   + (", flags packed into the done bytes" if args.packed_flags else "")
                                    + (f", randomized-reset curriculum over {args.curriculum} levels" if args.curriculum else "")
                                    + (f", outputs written zero-copy into a {args.ring}-slot on-device replay ring" if args.replay else ""),
                        "envs_per_gpu": E, "agents": N, "bodies": B, "curriculum_levels": args.curriculum, "replay": bool(args.replay), "parallelism": f"env-index shard x{world}", "mode": mode,

@@ -74,7 +74,11 @@ class StepArgs(ctypes.Structure):  # uavx_step_args
                 ("evaluate", ctypes.c_int32), ("reset_policy", ctypes.c_int32), ("step_cap", ctypes.c_uint32),
                 ("track_returns", ctypes.c_int32), ("seed", ctypes.c_uint64), ("obs", ctypes.c_void_p),
                 ("rew", ctypes.c_void_p), ("done", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p),
-                ("ended", ctypes.c_void_p), ("truncated", ctypes.c_void_p)]
+                ("ended", ctypes.c_void_p), ("truncated", ctypes.c_void_p), ("flags_mode", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+FLAGS_ARRAYS, FLAGS_IN_DONE = 0, 1
 
 
 class UWStepArgs(ctypes.Structure):  # uavx_uw_step_args

@@ -326,7 +326,7 @@ class BatchedMultiUAVWorld2D(_Base):
                  "all_done": _lib.RESET_ALL_DONE}
 
     def step_ex(self, actions, evaluate=False, polar=False, auto_reset=None, step_cap=0, track_returns=True,
-                out=None, flags_out=None):
+                out=None, flags_out=None, packed_flags=False):
         """env.step plus what the reference's trainer loops do around it, in the same launch:
           polar=True       actions are policy outputs a in [-1,1]^2, converted like test_sac_multi.py:77-80
           auto_reset       "agent0_done" (test_sac_multi.py:112) / "all_done" (:116,161) / None; step_cap (:17,67)
@@ -337,7 +337,11 @@ class BatchedMultiUAVWorld2D(_Base):
         info["ended"] (this call ended the env's episode) and info["truncated"] (it ended by the step cap alone: a
         time-limit cut to bootstrap through, not a terminal state).
         out=(obs, rew, done) / flags_out=(reset_mask, ended, truncated): caller-owned tensors the launch writes instead
-        of the env's own buffers (DeviceReplay hands in slots of its ring: nothing is copied afterwards)."""
+        of the env's own buffers (DeviceReplay hands in slots of its ring: nothing is copied afterwards).
+        packed_flags=True (UAVX_FLAGS_IN_DONE): no per-env flag arrays are written; `done` comes back as the raw uint8
+        tensor whose entry [e, 0] carries done | reset_mask << 1 | ended << 2 | truncated << 3 (the other agents' entries
+        are 0 / 1) -- one launch with no one-byte-per-env stores; unpack_done() splits it (four small torch ops, only when
+        the caller wants the flags)."""
         fast = (out is None and type(actions) is torch.Tensor and actions.shape == self._act_shape
                 and actions.is_contiguous() and actions.device == self.device and actions.dtype in _TORCH_DT)
         if fast:
@@ -365,9 +369,16 @@ class BatchedMultiUAVWorld2D(_Base):
             self._ex_ref = ctypes.byref(self._ex_args)
             self._ex_info = {"distance": 0, "reset_mask": self._reset_mask_bool[0], "ended": self._reset_mask_bool[1],
                              "truncated": self._reset_mask_bool[2]}
+            self._info_packed = {"distance": 0, "flags_in_done": True}
         args = self._ex_args  # one struct reused across calls: only the fields that change are written
         info = self._ex_info
-        if flags_out is not None:
+        args.flags_mode = _lib.FLAGS_IN_DONE if packed_flags else _lib.FLAGS_ARRAYS
+        if packed_flags:
+            if flags_out is not None:
+                raise ValueError("uavx: packed_flags=True writes no flag arrays; drop flags_out")
+            args.reset_mask = args.ended = args.truncated = None
+            info = self._info_packed
+        elif flags_out is not None:
             fl = [self._out(t.view(torch.uint8) if t.dtype == torch.bool else t, (self.num_envs,), torch.uint8, f"flags_out[{i}]")
                   for i, t in enumerate(flags_out)]
             args.reset_mask, args.ended, args.truncated = (t.data_ptr() for t in fl)
@@ -384,7 +395,14 @@ class BatchedMultiUAVWorld2D(_Base):
         rc = self._L.uavx_step_ex(self._h, self._ex_ref, self._stream())
         if rc:
             _lib.check(rc, self._h)
-        return obs, rew, done_bool, info
+        return obs, rew, (done if packed_flags else done_bool), info
+
+    @staticmethod
+    def unpack_done(done):
+        """Splits the uint8 `done` tensor of step_ex(packed_flags=True): -> (done [E, N] bool, reset_mask [E] bool,
+        ended [E] bool, truncated [E] bool)."""
+        first = done[:, 0]
+        return (done & 1).to(torch.bool), (first & 2).to(torch.bool), (first & 4).to(torch.bool), (first & 8).to(torch.bool)
 
     def episode_stats(self):
         """Statistics over the episodes ended so far (auto-reset or reset()): dict of [E] tensors

@@ -142,6 +142,7 @@ struct StepExtra {
     uint32_t seed_lo, seed_hi;
     uint8_t *reset_mask;
     uint8_t *ended, *truncated;
+    int flags_in_done;   // UAVX_FLAGS_IN_DONE: the three per-env flags travel in bits 1..3 of the env's first done byte
     int use_stage;   // consult the pre-drawn layouts
     // layouts drawn ahead: the first pf_blocks workgroups of the launch do not step anything -- they draw the layouts of the
     // NEXT episodes of one slice of the envs (see stage_ahead); env-workgroup w is workgroup pf_blocks + w
@@ -1361,8 +1362,8 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
     // The env record is loaded FIRST and the 48 B of agent state after it: vmcnt retires in issue order, so the
     // (rare) re-initialisation below can start as soon as the small load is back and runs underneath the
     // state loads of the launch-wide read burst.  The wave's step counter comes through the scalar cache.
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (m.active) rec = p.env_rec[m.e];
+    uint4 rec0 = make_uint4(0, 0, 0, 0);
+    if (m.active) rec0 = p.env_rec[m.e];
     const uint32_t wave_count = p.wave_steps[m.wave];
     __builtin_amdgcn_sched_barrier(0);
     if (m.active) {
@@ -1372,9 +1373,9 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         load_agent(p, m.a, s);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const bool do_reset = (rec.y & kRecEnded) != 0;
-    const uint32_t episode = rec.y & ~kRecEnded;
-    uint32_t steps_v = wave_count - rec.x;
+    const bool do_reset = (rec0.y & kRecEnded) != 0;
+    const uint32_t episode = rec0.y & ~kRecEnded;
+    uint32_t steps_v = wave_count - rec0.x;
     // Register budget (the variants with 8 agents / bodies sit at the 64-VGPR edge of 8 wavefronts per SIMD): a
     // re-initialised env's record is written straight over the loaded one (`s`), and what the statistics fold needs is
     // read back from `rec` and memory at the END of the launch, by the (rare) lanes that need it.
@@ -1499,25 +1500,33 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         if (!(EXT && (s.flags & kFlagInactive))) store_agent(p, m.a, s, flags_in);
         else if (do_reset) { p.pos[m.a] = make_float2(s.x, s.y); p.vel[m.a] = make_double2(0.0, 0.0); }  // parked at +inf
         rew_out[m.a] = rew;
-        done_out[m.a] = (uint8_t)dn;
+        // episode end test for the NEXT call (test_sac_multi.py:67,112,116); meaningful in the env's first lane
+        const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;
+        const bool terminal = (x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
+                              (x.reset_policy == UAVX_RESET_ALL_DONE && all_done);          // test_sac_multi.py:112,116
+        const bool capped = x.step_cap != 0 && steps_next >= x.step_cap;                   // :17,67
+        const bool ended = (terminal || capped) && !do_reset;
+        // UAVX_FLAGS_IN_DONE: reset_mask / ended / truncated ride in bits 1..3 of the done byte of the env's agent 0 -- a
+        // byte of a line this launch writes in full anyway -- instead of three more one-byte-per-env arrays, each a partial
+        // line write per env (A/B at 65 536 x 4: the three byte stores are 0.28 us of a 7 us launch)
+        uint32_t dbyte = dn;
+        if (x.flags_in_done && m.i == 0) dbyte |= (do_reset ? 2u : 0u) | (ended ? 4u : 0u) | ((ended && !terminal) ? 8u : 0u);
+        done_out[m.a] = (uint8_t)dbyte;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
         if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
         if (m.i == 0) {
-            // The env record is read AGAIN here by the one lane that rewrites it, instead of being carried through the step
-            // in four registers of every lane (nothing has written it since the load at the top of the launch): the step
-            // with scripted bodies fits 64 VGPRs that way, i.e. 8 wavefronts per SIMD and ONE resident round for the 8 192
-            // wavefronts of a 65 536-env launch (6 per SIMD = 1.4 rounds, the second one mostly idle: +2 us).
-            const uint4 rec = p.env_rec[m.e];
+            // With scripted bodies the env record is read AGAIN here by the one lane that rewrites it, instead of being
+            // carried through the step in four registers of every lane (nothing has written it since the load at the top of
+            // the launch): that kernel fits 64 VGPRs that way, i.e. 8 wavefronts per SIMD and ONE resident round for the
+            // 8 192 wavefronts of a 65 536-env launch.  The other variants have registers to spare and keep it.
+            const uint4 rec = EXT ? p.env_rec[m.e] : rec0;
             float2 run = do_reset ? make_float2(0.f, 0.f) : make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w));
-            const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;
-            const bool terminal = (x.reset_policy == UAVX_RESET_AGENT0_DONE && dn != 0) ||
-                                  (x.reset_policy == UAVX_RESET_ALL_DONE && all_done);      // test_sac_multi.py:112,116
-            const bool capped = x.step_cap != 0 && steps_next >= x.step_cap;               // :17,67
-            const bool ended = (terminal || capped) && !do_reset;
-            if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
-            if (x.ended) x.ended[m.e] = ended ? 1 : 0;
-            if (x.truncated) x.truncated[m.e] = (ended && !terminal) ? 1 : 0;
+            if (!x.flags_in_done) {
+                if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
+                if (x.ended) x.ended[m.e] = ended ? 1 : 0;
+                if (x.truncated) x.truncated[m.e] = (ended && !terminal) ? 1 : 0;
+            }
             uint4 out = rec;
             if (do_reset) {  // fold the ended episode, start the new one: steps == 0 after this launch (MUW:166)
                 fold_store(p, m.e, wave_count - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold_load(p, m.e));
@@ -2387,6 +2396,8 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown action_mode");
     if (a->reset_policy < UAVX_RESET_NEVER || a->reset_policy > UAVX_RESET_ALL_DONE)
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown reset_policy");
+    if (a->flags_mode != UAVX_FLAGS_ARRAYS && a->flags_mode != UAVX_FLAGS_IN_DONE)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: unknown flags_mode");
     if ((reinterpret_cast<uintptr_t>(a->obs) & 15u) || (reinterpret_cast<uintptr_t>(a->actions) & (a->action_dtype == UAVX_F64 ? 15u : 7u)) ||
         (reinterpret_cast<uintptr_t>(a->rew) & 3u))
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_step_ex: obs must be 16-byte aligned, actions 8 (float32) / 16 (float64), rew 4");
@@ -2405,6 +2416,7 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.step_cap = a->step_cap; x.seed_lo = (uint32_t)a->seed; x.seed_hi = (uint32_t)(a->seed >> 32);
     x.reset_mask = a->reset_mask;
     x.ended = a->ended; x.truncated = a->truncated;
+    x.flags_in_done = (a->flags_mode == UAVX_FLAGS_IN_DONE) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid = wave_grid(h);
     // auto-resetting call: the launch carries staging workgroups that draw the layouts of the next episodes (stage_ahead)

@@ -14,13 +14,22 @@ from . import _lib
 
 
 class DeviceReplay:
-    def __init__(self, env, horizon, num_learners=None):
+    def __init__(self, env, horizon, num_learners=None, packed_flags=False):
         """env: BatchedMultiUAVWorld2D; horizon: number of most recent steps kept (capacity in
         transitions = horizon * num_envs * num_learners).  num_learners: only agents [0, num_learners)
-        are sampled; default all (scripted bodies created with num_bodies=... are not agents and never appear here)."""
+        are sampled; default all (scripted bodies created with num_bodies=... are not agents and never appear here).
+        packed_flags=True: the launches run with UAVX_FLAGS_IN_DONE -- "re-initialised", "ended" and "truncated" ride in
+        bits 1..3 of the done byte of every env's agent 0 inside the ring's done rows (step() then returns the raw uint8
+        done row), and the skip / ended / trunc rows below are not written by the launches at all."""
         self.env, self.T = env, int(horizon)
         self.num_learners = env.num_agents if num_learners is None else int(num_learners)
+        self.packed = bool(packed_flags)
         L, E, N, dev = self.T + 1, env.num_envs, env.num_agents, env.device
+        if (E * N * _lib.OBS_DIM * 4) % 16:
+            # the step launch writes every observation slot with 16-byte stores: each slot of the ring must start on a
+            # 16-byte boundary (an odd number of agent slots would put every other one 8 bytes off)
+            raise ValueError(f"uavx: DeviceReplay needs num_envs * num_agents even (got {E} x {N}): observation slots of "
+                             "the ring are written with 16-byte stores")
         self.L = L
         self.obs = torch.zeros((L, E, N, _lib.OBS_DIM), dtype=torch.float32, device=dev)
         self.act = torch.zeros((L, E, N, 2), dtype=torch.float32, device=dev)
@@ -53,10 +62,21 @@ class DeviceReplay:
         if actions is not None:
             self.act[k].copy_(actions)
         nxt = (self.count + 1) % self.L
-        obs, rew, done, info = self.env.step_ex(self.act[k], out=(self.obs[nxt], self.rew[k], self.done[k]),
-                                                flags_out=(self.skip[k], self.ended[k], self.trunc[k]), **step_ex_kwargs)
+        if self.packed:
+            obs, rew, done, info = self.env.step_ex(self.act[k], out=(self.obs[nxt], self.rew[k], self.done[k]),
+                                                    packed_flags=True, **step_ex_kwargs)
+        else:
+            obs, rew, done, info = self.env.step_ex(self.act[k], out=(self.obs[nxt], self.rew[k], self.done[k]),
+                                                    flags_out=(self.skip[k], self.ended[k], self.trunc[k]), **step_ex_kwargs)
         self.count += 1
         return obs, rew, done, info
+
+    def _flags(self, s, e):
+        """(skip, truncated, ended) bool tensors of ring rows s, envs e."""
+        if self.packed:
+            b = self.done[s, e, 0]
+            return (b & 2) != 0, (b & 8) != 0, (b & 4) != 0
+        return self.skip[s, e] != 0, self.trunc[s, e] != 0, self.ended[s, e] != 0
 
     def reset(self, mask=None, **reset_kwargs):
         """A manual (masked) env.reset() between two steps: the fresh observations replace s(k) in the ring, so the
@@ -64,18 +84,23 @@ class DeviceReplay:
         obs = self.env.reset(mask=mask, out=self.obs[self.count % self.L], **reset_kwargs)
         if self.count > 0:
             prev = (self.count - 1) % self.L
-            if mask is None:
+            m = None if mask is None else torch.as_tensor(mask, device=self.env.device).to(torch.uint8)
+            if self.packed:
+                self.done[prev, :, 0] |= 2 if m is None else (m != 0).to(torch.uint8) * 2
+            elif m is None:
                 self.skip[prev].fill_(1)
             else:
-                self.skip[prev] |= torch.as_tensor(mask, device=self.env.device).to(torch.uint8)
+                self.skip[prev] |= m
         return obs
 
     def sample(self, batch_size, generator=None, with_flags=False):
         """Uniform batch of transitions like ReplayMemory.sample (replay_memory.py:21-24):
         (state [B,10], action [B,2], reward [B], next_state [B,10], mask [B] = 1 - done); with_flags=True appends
         (truncated [B] bool, ended [B] bool) of the env at that transition.  Fixed size, no host sync.
-        Rows where the env was re-initialised instead of stepped are never returned: a drawn row that hits one is
-        redrawn once, and what is still invalid after that takes the place of a valid row of the same batch."""
+        Rows where the env was re-initialised instead of stepped are not transitions: a drawn row that hits one is
+        redrawn once, and what is still invalid after that is replaced by a valid row of the same batch.  Only when NO row
+        of the batch is valid after the redraw (a tiny batch right after a reset of every env) does a re-initialisation row
+        come back -- recognisable by reward 0 and mask 1 with `ended` False; draw a larger batch or step first."""
         assert self.count > 0
         E, N, dev = self.env.num_envs, self.num_learners, self.env.device
         lo = max(0, self.count - self.T)
@@ -88,9 +113,9 @@ class DeviceReplay:
 
         k, e, i = draw()
         k2, e2, i2 = draw()  # one redraw for rows that hit a reset step (rare: one per episode per env)
-        bad = self.skip[k % self.L, e] != 0
+        bad = self._flags(k % self.L, e)[0]
         k, e, i = torch.where(bad, k2, k), torch.where(bad, e2, e), torch.where(bad, i2, i)
-        valid = self.skip[k % self.L, e] == 0
+        valid = ~self._flags(k % self.L, e)[0]
         # still invalid (both draws hit reset rows): duplicate the nearest valid row of this batch -- never a row outside
         # [lo, count - 1] and never a reset row (a neighbouring STEP is not safe: with step_cap=1, or after a manual
         # reset, reset rows can be adjacent, and count itself is not written yet)
@@ -101,7 +126,8 @@ class DeviceReplay:
         k, e, i = k[src], e[src], i[src]
         s, s1 = k % self.L, (k + 1) % self.L
         out = (self.obs[s, e, i], self.act[s, e, i], self.rew[s, e, i], self.obs[s1, e, i],
-               1.0 - self.done[s, e, i].float())
+               1.0 - (self.done[s, e, i] & 1).float())
         if with_flags:
-            out = out + (self.trunc[s, e] != 0, self.ended[s, e] != 0)
+            _, tr, en = self._flags(s, e)
+            out = out + (tr, en)
         return out

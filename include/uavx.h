@@ -222,6 +222,8 @@ typedef enum {
     UAVX_RESET_ALL_DONE = 2     /* test_sac_multi.py:116,161 */
 } uavx_reset_policy;
 
+typedef enum { UAVX_FLAGS_ARRAYS = 0, UAVX_FLAGS_IN_DONE = 1 } uavx_flags_mode;
+
 typedef struct {
     const void *actions;   /* [E*N*2] */
     int32_t action_dtype;  /* uavx_dtype */
@@ -242,6 +244,13 @@ typedef struct {
      * be NULL.  A call that re-initialises an env reports 0 / 0 for it. */
     uint8_t *ended;        /* [E] or NULL */
     uint8_t *truncated;    /* [E] or NULL */
+    /* ABI version 3 (appended).  UAVX_FLAGS_IN_DONE: the three per-env flags are NOT written to reset_mask / ended /
+     * truncated (which are ignored and may be NULL) but ride in the done byte of the env's agent 0:
+     *     done[e*N + 0] = done | reset_mask << 1 | ended << 2 | truncated << 3        (the other agents' bytes stay 0 / 1)
+     * so that a launch has no one-byte-per-env partial line writes (0.3 us of a 7 us launch at 65 536 x 4); readers take
+     * done & 1.  UAVX_FLAGS_ARRAYS (0, the default: a zero-filled struct behaves like version 2) keeps the three arrays. */
+    int32_t flags_mode;    /* uavx_flags_mode */
+    int32_t reserved;
 } uavx_step_args;
 
 /* Auto-reset is "next-step": an env whose episode ended at call t keeps its terminal observation in

@@ -109,6 +109,47 @@ def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, policy, code, c
     env.close()
 
 
+@pytest.mark.parametrize("n,bodies,policy,code,cap", [(4, 0, "agent0_done", 1, 40), (8, 16, "all_done", 2, 25), (5, 0, None, 0, 7), (1, 0, "agent0_done", 1, 3)])
+def test_flags_packed_into_the_done_byte_vs_oracle(amd, oracle_mod, n, bodies, policy, code, cap):
+    """uavx_step_ex with flags_mode = UAVX_FLAGS_IN_DONE (ABI v3): reset_mask / ended / truncated in bits 1..3 of the done byte
+    of every env's agent 0, no flag arrays written.  Done bits, the three flags, state, observations and rewards against the
+    oracle, and against a twin handle driven with the three plain arrays (the same launch otherwise: outputs bit for bit)."""
+    import torch
+    E = 2048
+    kw = dict(x_size=24.0, y_size=24.0, num_agents=n, d_sense=9.0, **(dict(num_bodies=bodies, body_period=8) if bodies else {}))
+    env = amd.BatchedMultiUAVWorld2D(E, seed=5, env_offset=3, **kw)
+    twin = amd.BatchedMultiUAVWorld2D(E, seed=5, env_offset=3, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.reset(); twin.reset(); orc.reset_philox(5, env_offset=3)
+    rng = np.random.default_rng(11)
+    seen = np.zeros(3, np.int64)
+    for t in range(120):
+        a = rng.uniform(-1, 1, size=(E, n, 2)).astype(np.float32)
+        ad = torch.from_numpy(a).to(env.device)
+        obs_g, rew_g, done_raw, info = env.step_ex(ad, polar=True, auto_reset=policy, step_cap=cap, packed_flags=True)
+        assert done_raw.dtype == torch.uint8 and info.get("flags_in_done") is True
+        obs_t, rew_t, done_t, info_t = twin.step_ex(ad, polar=True, auto_reset=policy, step_cap=cap)
+        obs_o, rew_o, done_o, rm_o, en_o, tr_o = orc.step_ex(a, action_mode=1, reset_policy=code, step_cap=cap, seed=5, env_offset=3, with_end=True)
+        raw = _np(done_raw)
+        assert (raw[:, 1:] <= 1).all() and (raw[:, 0] < 16).all()                 # flags only in agent 0's byte
+        done_g, rm_g, en_g, tr_g = (_np(x) for x in env.unpack_done(done_raw))
+        ctx = f"step {t}"
+        np.testing.assert_array_equal(done_g.astype(np.uint8), done_o, err_msg=ctx)
+        np.testing.assert_array_equal(rm_g.astype(np.uint8), rm_o, err_msg=ctx)
+        np.testing.assert_array_equal(en_g.astype(np.uint8), en_o, err_msg=ctx)
+        np.testing.assert_array_equal(tr_g.astype(np.uint8), tr_o, err_msg=ctx)
+        assert torch.equal(obs_g, obs_t) and torch.equal(rew_g, rew_t) and np.array_equal(done_g, _np(done_t))
+        assert np.array_equal(rm_g, _np(info_t["reset_mask"])) and np.array_equal(en_g, _np(info_t["ended"])) and np.array_equal(tr_g, _np(info_t["truncated"]))
+        assert obs_err(_np(obs_g), obs_o) <= TOL and float(np.abs(_np(rew_g) - rew_o).max()) <= TOL, ctx
+        seen += [int(rm_o.sum()), int(en_o.sum()), int(tr_o.sum())]
+    assert (seen > 0).all(), seen
+    for key, v in env.get_state().items():
+        assert torch.equal(v, twin.get_state()[key]), key
+    with pytest.raises(ValueError):
+        env.step_ex(ad, packed_flags=True, flags_out=(torch.zeros(E, dtype=torch.uint8, device=env.device),) * 3)
+    env.close(); twin.close()
+
+
 def test_curriculum_set_config_between_launches_vs_oracle(amd, oracle_mod):
     """uavx_set_config: world scalars change between launches (box shrinks, sensing range / collider / speed
     limits move); the same schedule on the oracle gives the same masks, states and reset streams."""

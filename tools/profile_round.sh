@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/prof/<shape>/<pass>/ (run on the GPU box through gpurun), then
 #   python tools/summarize_profiles.py rNN   condenses it into profiles/.
-# usage: tools/profile_round.sh [calib] [ExN[+B][f][cL][r] | uwE ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f 65536x8+16fc4r uw1048576
+# usage: tools/profile_round.sh [calib] [ExN[+B][f][cL][r][p] | uwE ...]     e.g.  tools/profile_round.sh calib 65536x4 65536x8+16 65536x4f 65536x8+16fc4r uw1048576
 #        (+B: scripted bodies; f: the fused uavx_step_ex path with polar actions, auto-reset and statistics; cL: L-level
 #         curriculum; r: outputs into the on-device replay ring -- 65536x8+16fc4r is bench.py --cfg5)
 # Kernel trace and each counter group are separate runs (counter collection serialises and slows kernels); the
@@ -34,6 +34,7 @@ for arg in "$@"; do
     BARGS="--world uw --envs ${arg#uw} --ring 8 --no-cpu-baseline --no-large"
   else
     fused=""; a=$arg; extra=""
+    [[ "$a" == *p ]] && { extra="$extra --packed-flags"; a=${a%p}; }                             # ...p: flags packed into the done bytes
     [[ "$a" == *r ]] && { extra="$extra --replay"; a=${a%r}; }                                  # ...r: outputs into the replay ring
     [[ "$a" =~ c([0-9]+)$ ]] && { extra="$extra --curriculum ${BASH_REMATCH[1]}"; a=${a%c*}; }   # ...cL: L-level curriculum
     [[ "$a" == *f ]] && { fused="--fused"; a=${a%f}; }
