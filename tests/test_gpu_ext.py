@@ -8,6 +8,8 @@ levels and counters, 1e-5 on observations / rewards -- with the learners' own st
 extension handle with no bodies and one level equal to the config must reproduce the plain kernels bit for bit)."""
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 
@@ -234,9 +236,10 @@ def test_explicit_env_levels_and_parked_learners(amd, oracle_mod):
 
 
 def test_config5_full_size_properties(amd):
-    """configs[4] at BASELINE size (65 536 envs x 8 learners + 16 bodies), where the oracle is too slow to follow every
-    env: size-independent properties -- determinism, independence of the shard cut (Philox keyed by global env id),
-    bodies stay inside their env's box, parked / active bookkeeping is consistent -- plus an oracle check on a slice."""
+    """configs[4] at BASELINE size (65 536 envs x 8 learners + 16 bodies): size-independent properties -- determinism,
+    independence of the shard cut (Philox keyed by global env id), bodies stay inside their env's box, parked / active
+    bookkeeping is consistent.  GPU against GPU; the comparison with the oracle at this size is
+    test_config5_full_size_oracle_differential below."""
     import torch
     E, L, B = 65536, 8, 16
     kw = dict(num_agents=L, num_bodies=B, body_period=32, body_seed=5)
@@ -279,6 +282,39 @@ def test_config5_full_size_properties(amd):
     parked = (st["flags"] & 32) != 0
     assert torch.equal(parked, torch.arange(L, device=bodies.device)[None, :] >= nl[:, None])
     assert len(torch.unique(lv)) == 3
+
+
+def test_config5_full_size_oracle_differential(amd, oracle_mod):
+    """configs[4] at BASELINE size against the ORACLE, every env: 65 536 envs x (8 learners + 16 bodies), 3-level randomized-
+    reset curriculum, fused step_ex with polar commands, all-done auto-reset and a step cap of 12 (so that every env is
+    re-initialised from a parked layout -- or draws in place -- two or three times), 36 steps: reset / ended / truncated
+    masks, done masks, levels, learner state, body records and counters bit for bit, observations / rewards to 1e-5."""
+    import torch
+    E, L, B, T, cap = 65536, 8, 16, 36, 12
+    nthreads = os.cpu_count() or 8
+    kw = dict(num_agents=L, num_bodies=B, body_period=8, body_seed=5)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=13, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=nthreads, **kw)
+    env.set_curriculum(LEVELS, lo=0, hi=2); orc.set_curriculum(LEVELS, lo=0, hi=2)
+    env.reset(); orc.reset_philox(13)
+    rng = np.random.default_rng(9)
+    n_reset = n_trunc = 0
+    for t in range(T):
+        a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
+        o_g, r_g, d_g, info = env.step_ex(torch.from_numpy(a).to(env.device), polar=True, auto_reset="all_done", step_cap=cap, evaluate=True)
+        o_o, r_o, d_o, rm_o, en_o, tr_o = orc.step_ex(a, evaluate=True, action_mode=1, reset_policy=2, step_cap=cap, seed=13, with_end=True)
+        ctx = f"step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(info["ended"]).astype(np.uint8), en_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(info["truncated"]).astype(np.uint8), tr_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(d_g).astype(np.uint8), d_o, err_msg=ctx)
+        assert obs_err(_np(o_g), o_o) <= TOL and float(np.abs(_np(r_g) - r_o).max()) <= TOL, ctx
+        if t % 6 == 5 or t == T - 1:
+            np.testing.assert_array_equal(_np(env.env_levels()), orc.level, err_msg=ctx)
+            _compare_state(env, orc, ctx)
+        n_reset += int(rm_o.sum()); n_trunc += int(tr_o.sum())
+    assert n_reset >= 2 * E and n_trunc >= E, (n_reset, n_trunc)
+    env.close()
 
 
 def test_extension_fixture_replay_on_device(amd):

@@ -3,6 +3,8 @@ host layer, against (a) the committed fixtures generated from the reference and 
 on seeded random batches.  Bar (BASELINE.json north_star): done/collision masks, flags, counters and
 float32 positions BIT-EXACT; float32 observations / rewards within 1e-5 (angle features measured on
 the circle)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -321,7 +323,8 @@ def test_step_k_equals_k_steps(amd, n, E):
 def test_full_size_properties(amd):
     """BASELINE.json's headline size (65 536 envs x 4 UAVs): size-independent properties —
     determinism, env independence (any sub-batch evolves identically inside the full batch) and
-    shard independence (env_offset keys the Philox streams by global env id)."""
+    shard independence (env_offset keys the Philox streams by global env id).  GPU against GPU; the comparison with the
+    oracle at this size is test_full_size_oracle_differential below."""
     import torch
     E, n, T = 65536, 4, 40
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -355,6 +358,48 @@ def test_full_size_properties(amd):
     assert torch.equal(full[3]["counters"][:, 1].long(), (flags & 1).sum(dim=1).long()), "reach count == done agents"
     assert torch.isfinite(full[0]).all() and float(full[0][..., [0, 2, 4, 7]].min()) >= 0.0
     assert float(full[0][..., [0, 1, 3, 4, 5, 6, 7, 8, 9]].abs().max()) <= 1.0 + 1e-6  # only the target distance may exceed 1
+
+
+def test_full_size_oracle_differential(amd, oracle_mod):
+    """BASELINE.json's headline size against the ORACLE, every env: 65 536 envs x 4 UAVs, Philox reset (a quarter of the envs
+    then get targets 0.8 - 1.6 m from their UAVs, through set_state on both sides, so that arrivals happen within the run), 64
+    steps of goal-seeking + noise commands -- arrivals, collisions and out-of-box terminations all occur: done masks at every
+    step, positions, velocities, flags and counters bit for bit, observations / rewards to 1e-5.  The oracle runs on all host
+    cores (~0.5 s for the 4.2 M env-steps; most of the test's time is numpy building the commands)."""
+    import torch
+    E, n, T = 65536, 4, 64
+    nthreads = os.cpu_count() or 8
+    env = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=99)
+    orc = oracle_mod.OracleMulti(num_envs=E, num_agents=n, nthreads=nthreads)
+    env.reset(); orc.reset_philox(99)
+    rng = np.random.default_rng(5)
+    st0 = orc.get_state()
+    near = np.arange(E) % 4 == 0
+    ang, rad = rng.uniform(-np.pi, np.pi, size=(E, n)), rng.uniform(0.8, 1.6, size=(E, n))
+    tgt = st0["tgt"].copy()
+    tgt[near] = (st0["loc"] + np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=-1).astype(np.float32))[near]
+    dd = tgt - st0["loc"]                                                  # float32, like MUW:154
+    init = np.sqrt(dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]).astype(np.float32)
+    env.set_state(tgt=tgt, init_d=init, prev_d=init); orc.set_state(tgt=tgt, init_d=init, prev_d=init)
+    assert obs_err(_np(env.observe()), orc.observe()) <= TOL
+    reached = collided = 0
+    for t in range(T):
+        d = orc.tgt - orc.loc
+        dist = np.linalg.norm(d, axis=-1, keepdims=True)
+        act = d / np.maximum(dist, 1e-9) * np.where(dist > 0.3, np.minimum(8.0, np.sqrt(4.0 * dist)), 0.0)
+        act = (act + rng.normal(0, 1.0, size=d.shape) * (dist > 2.0)).astype(np.float32)
+        o_g, r_g, d_g, _ = env.step(torch.from_numpy(act).to(env.device))
+        o_o, r_o, d_o = orc.step(act)
+        np.testing.assert_array_equal(_np(d_g).astype(np.uint8), d_o, err_msg=f"done mask, step {t}")
+        assert obs_err(_np(o_g), o_o) <= TOL and float(np.abs(_np(r_g) - r_o).max()) <= TOL, f"step {t}"
+        if t % 16 == 15 or t == T - 1:
+            st, ref = env.get_state(), orc.get_state()
+            for key in ("loc", "vel", "tgt", "init_d", "prev_d", "flags"):
+                np.testing.assert_array_equal(_np(st[key]), ref[key], err_msg=f"{key}, step {t}")
+            np.testing.assert_array_equal(_np(st["counters"]), ref["counters"].astype(np.int32), err_msg=f"counters, step {t}")
+    reached, collided = int(orc.counters[:, 1].sum()), int(orc.counters[:, 2].sum())
+    assert reached > 0 and collided > 0, (reached, collided)
+    env.close()
 
 
 def test_config3_eight_shards_equal_one_batch(amd):
