@@ -35,6 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 L3_BYTES = 256 * 2 ** 20       # Infinity Cache
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9               # peak engine clock
+VALU_CYCLES = 4                # a wave64 float32 VALU instruction occupies its SIMD for 4 cycles (float64 and transcendental ones longer)
 
 
 def algorithmic_bytes_per_env_step(n_agents, n_bodies=0, active_agents=None, active_bodies=None):
@@ -48,11 +51,11 @@ def algorithmic_bytes_per_env_step(n_agents, n_bodies=0, active_agents=None, act
     return 107 * na + 45 * (n_agents - na) + 24 + 32 * nb
 
 
-def measured_traffic(kernel_name, shape):
-    """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json, written by
-    tools/summarize_profiles.py from separate FETCH_SIZE / WRITE_SIZE runs of tools/profile_round.sh).  A summary is only
+def measured_pmc(kernel_name, shape):
+    """The entry of this kernel and workload shape in the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json, written
+    by tools/summarize_profiles.py from the separate counter runs of tools/profile_round.sh), or None.  A summary is only
     used when it was taken from THIS build of the kernels (hash of csrc/ + include/) and for this kernel and workload
-    shape ("ExN[+B][f]"): a stale file yields None rather than a number that no longer describes the code."""
+    shape ("ExN[+B][f]..."): a stale file yields None rather than numbers that no longer describe the code."""
     import glob
     from gym_uav_collision_avoidance_amd import _lib
     sha = _lib.source_hash()
@@ -65,10 +68,33 @@ def measured_traffic(kernel_name, shape):
         for entry in (d.get("kernels") or [d]):
             meta = entry.get("_meta", {})
             if (meta.get("csrc_sha") == sha and meta.get("shape") == shape
-                    and str(meta.get("kernel", "")).replace("void ", "").startswith(kernel_name)
-                    and "hbm_traffic_bytes_per_launch" in entry):
-                best = (entry["hbm_traffic_bytes_per_launch"]["total"], os.path.basename(f))
+                    and str(meta.get("kernel", "")).replace("void ", "").startswith(kernel_name)):
+                best = (entry, os.path.basename(f))
     return best
+
+
+def measured_traffic(kernel_name, shape):
+    """HBM bytes per step launch (FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) -> (bytes, file)."""
+    hit = measured_pmc(kernel_name, shape)
+    if hit and "hbm_traffic_bytes_per_launch" in hit[0]:
+        return hit[0]["hbm_traffic_bytes_per_launch"]["total"], hit[1]
+    return None
+
+
+def valu_roofline(kernel_name, shape, kernel_s):
+    """The instruction-issue ceiling next to the bandwidth one, for shapes that are not bandwidth-bound: SQ_INSTS_VALU (wave-level
+    vector instructions of one launch, PMC) x 4 cycles each, spread over 1 024 SIMDs at 2.4 GHz = the time the launch needs
+    for VALU issue alone if every SIMD issued one vector instruction every 4 cycles without a bubble (a floor on that time:
+    float64 and transcendental instructions take longer).  frac = that time / the launch's duration."""
+    hit = measured_pmc(kernel_name, shape)
+    if not hit or "SQ_INSTS_VALU" not in hit[0] or "SQ_WAVES" not in hit[0]:
+        return None
+    insts, waves = hit[0]["SQ_INSTS_VALU"]["median"], hit[0]["SQ_WAVES"]["median"]
+    t = insts * VALU_CYCLES / (SIMDS * CLOCK_HZ)
+    return dict(bound="valu", valu_insts_per_wave=insts / waves, waves=waves, issue_time_us=t * 1e6, kernel_us=kernel_s * 1e6,
+                frac=t / kernel_s, source=hit[1],
+                note=f"SQ_INSTS_VALU x {VALU_CYCLES} cycles / ({SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz): the floor of the launch's "
+                     "vector-issue time; float64 / transcendental instructions occupy a SIMD longer than 4 cycles")
 
 
 def polar_actions(gen, shape, vmax_norm, device):
@@ -79,33 +105,51 @@ def polar_actions(gen, shape, vmax_norm, device):
     return torch.stack([v * torch.cos(th), v * torch.sin(th)], dim=-1).contiguous()
 
 
-def cpu_baseline(n_agents, n_bodies=0, budget_s=12.0):
-    """The CPU oracle (a C port of the reference's step, oracle/uavx_oracle.c) timed on this box's
-    host cores on a bounded sample of the same workload: 4 096 envs x n_agents (+ n_bodies scripted bodies),
-    same reset seed and action distribution."""
+def cpu_baseline(n_agents, n_bodies=0, budget_s=18.0):
+    """The CPU oracle (a C port of the reference's step, oracle/uavx_oracle.c) timed on this box's host cores on a bounded
+    sample of the same workload: same reset seed and action distribution, OpenMP over envs on ALL host cores (SURVEY.md 8d:
+    that is the baseline `speedup_vs_cpu_baseline` is taken against), with the 16-thread and the single-thread (the
+    reference's own shape: it cannot use a second core) figures beside it.  The batch is sized to the thread count
+    (>= 64 envs per thread, at least 4 096), so that every core has work."""
     import oracle
     oracle.build()
-    cores = min(os.cpu_count() or 1, 16)
-    E = 4096
+    host = os.cpu_count() or 1
+    try:
+        host = len(os.sched_getaffinity(0))     # the cores this process may be scheduled on
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:                                         # ... and the CPU time it is granted (cgroup v2): "quota period" or "max period"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    if quota is not None and quota < host:       # threads beyond the quota are only throttled: they measure the throttle
+        host = quota
     rng = np.random.default_rng(1234)
-    a = rng.uniform(-1, 1, size=(8, E, n_agents, 2))
-    v = (a[..., 0] / 2 + 0.5) * np.sqrt(200.0)
-    acts = np.stack([v * np.cos(a[..., 1] * np.pi), v * np.sin(a[..., 1] * np.pi)], axis=-1)
-    out = {}
-    for label, threads in (("1", 1), ("all", cores)):
+    out, sizes = {}, {}
+    runs = [("all", host)] + ([("16", 16)] if host > 16 else []) + [("1", 1)]
+    for label, threads in runs:
+        E = max(4096, 64 * threads)
+        a = rng.uniform(-1, 1, size=(4, E, n_agents, 2))
+        v = (a[..., 0] / 2 + 0.5) * np.sqrt(200.0)
+        acts = np.stack([v * np.cos(a[..., 1] * np.pi), v * np.sin(a[..., 1] * np.pi)], axis=-1)
         orc = oracle.OracleMulti(num_envs=E, num_agents=n_agents, nthreads=threads, num_bodies=n_bodies)
         orc.reset_philox(0)
         for k in range(3):
-            orc.step(acts[k % 8])
+            orc.step(acts[k % 4])
         t0 = time.perf_counter()
         steps = 0
         while True:
-            for k in range(8):
+            for k in range(4):
                 orc.step(acts[k])
-            steps += 8
-            if time.perf_counter() - t0 > budget_s / 2:
+            steps += 4
+            if time.perf_counter() - t0 > budget_s / len(runs):
                 break
         out[label] = E * steps / (time.perf_counter() - t0)
+        sizes[label] = E
+    cores = host
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -115,9 +159,14 @@ def cpu_baseline(n_agents, n_bodies=0, budget_s=12.0):
     except OSError:
         pass
     res = dict(value=out["all"], unit="env-steps/s", cores=cores, kind="port", cpu_model=model, host_cpus=os.cpu_count(),
-               sample=f"{E} envs x {n_agents} UAVs" + (f" + {n_bodies} scripted bodies" if n_bodies else "") +
-                      f", oracle/uavx_oracle.c with OpenMP over envs on {cores} threads, ~{budget_s / 2:.0f} s",
-               single_thread_value=out["1"])
+               sample=f"{sizes['all']} envs x {n_agents} UAVs" + (f" + {n_bodies} scripted bodies" if n_bodies else "") +
+                      f", oracle/uavx_oracle.c with OpenMP over envs on all {cores} host threads, ~{budget_s / len(runs):.0f} s per run",
+               single_thread_value=out["1"], threads16_value=out.get("16"), cpu_quota=quota,
+               note="value = every core this job may use: min(schedulable CPUs, cgroup cpu.max quota) -- on a one-GPU box of this pool "
+                    "that is 16 of the host's 256 hardware threads (more threads are throttled, not run); threads16_value / "
+                    "single_thread_value: the same port on 16 threads / on one (the reference itself is single-threaded Python: "
+                    "reference_python); value_if_whole_host: linear extrapolation to host_cpus, an upper bound never measured")
+    res["value_if_whole_host"] = out["all"] * (os.cpu_count() or cores) / cores
     # the unmodified Python reference cannot travel to the GPU box: its timing is taken in the build container by
     # tools/time_reference.py and attached here with its provenance
     import glob
@@ -255,8 +304,13 @@ def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60)
     env.close()
     del ring, env
     torch.cuda.empty_cache()
+    shape = f"{E}x{N}" + (f"+{bodies}" if bodies else "")
+    nt = N if (N in (1, 2, 4, 8) and not bodies) else 0
+    traffic = measured_traffic(f"uavx::step_kernel<{nt}", shape)
     return dict(bound="hbm", achieved=b / kernel_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b / kernel_s / 1e9 / HBM_PEAK_GBS,
-                traffic=None, bytes_per_launch=b, kernel_us=kernel_s * 1e6, envs=E, agents=N, steps=steps,
+                traffic=traffic[0] if traffic else None, traffic_source=traffic[1] if traffic else None,
+                achieved_traffic=(traffic[0] / kernel_s / 1e9) if traffic else None,
+                bytes_per_launch=b, kernel_us=kernel_s * 1e6, envs=E, agents=N, steps=steps,
                 working_set_bytes=ws, note="working set >> 256 MiB Infinity Cache: HBM-resident stream; "
                                            "achievable HBM rate on MI355X is ~6.3 TB/s (0.79 of the 8 TB/s spec peak)")
 
@@ -556,6 +610,17 @@ def main():
             "episode_metrics": summ,
             "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + len(devs)),
         }
+        if args.world == "multi":
+            rv = valu_roofline(kernel_name, shape, kernel_s)
+            if rv is not None:
+                line["roofline_valu"] = rv
+                if rv["valu_insts_per_wave"] > 600 and rv["frac"] > line["roofline"]["frac"]:
+                    # the instruction-issue ceiling is the nearer one: say so, and keep the bandwidth figures beside it
+                    line["roofline"]["bound_note"] = (f"nearer ceiling: vector-instruction issue ({rv['frac']:.2f} of the launch) -- see "
+                                                      "roofline_valu; `bound` stays the contract's HBM figure computed from algorithmic bytes")
+                    line["roofline"]["nearer_bound"] = "valu"
+                else:
+                    line["roofline"]["nearer_bound"] = "hbm"
         if world == 1 and K < 500 and not args.no_large:
             # A K-step region this short holds one graph replay whose launch latency (~10-15 us) is a visible share of it;
             # the same kernel over a 1000-step region of its own (not part of `value`) for the steady per-launch time
@@ -584,6 +649,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.world == "multi":
             line["cpu_baseline"] = cpu_baseline(N, B)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            line["speedup_vs_cpu_baseline_if_whole_host"] = value / line["cpu_baseline"]["value_if_whole_host"]
         print(json.dumps(line), flush=True)
     env.close()
     if distributed:
