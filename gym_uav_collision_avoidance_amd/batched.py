@@ -523,6 +523,43 @@ class BatchedMultiUAVWorld2D(_Base):
         _lib.check(self._L.uavx_get_state_f64(self._h, ctypes.byref(view), self._stream()), self._h)
         return st
 
+    # -- exact snapshot / restore (uavx_save / uavx_load) -------------------------------------------------------------
+    def state_dict(self):
+        """Everything needed to continue this batch bit for bit: {"snapshot": uint8 device tensor written by uavx_save (agent
+        state, counters, running and ended-episode statistics, bodies, levels, parked auto-reset layouts, world / body rule /
+        curriculum / staging parameters), "host": the few Python-side values (seed, constructor shape)}.  The reference
+        checkpoints only its agents (sac.py:101-139); with this a 65 536-env run resumes where it stopped.  torch.save-able."""
+        n = int(self._L.uavx_snapshot_bytes(self._h))
+        blob = torch.empty((n + 256,), dtype=torch.uint8, device=self.device)
+        off = (-blob.data_ptr()) % 256                       # uavx_save wants a 256-byte aligned buffer
+        snap = blob[off:off + n]
+        _lib.check(self._L.uavx_save(self._h, snap.data_ptr(), self._stream()), self._h)
+        host = dict(num_envs=self.num_envs, num_agents=self.num_agents, num_bodies=self.num_bodies, env_offset=self.env_offset,
+                    seed=self.seed, levels=self.levels, body_rule=getattr(self, "body_rule", None),
+                    world=dict(x_size=self.x_size, y_size=self.y_size, max_speed=float(self.max_speed[0]),
+                               max_acceleration=float(self.max_acceleratoin[0]), collider_radius=self.collider_radius,
+                               d_sense=self.d_sense))
+        return {"snapshot": snap, "host": host}
+
+    def load_state_dict(self, sd):
+        """Restores a state_dict() of a batch of the same shape (envs, learners, bodies); waits for the current stream once."""
+        host = sd["host"]
+        if (host["num_envs"], host["num_agents"], host["num_bodies"]) != (self.num_envs, self.num_agents, self.num_bodies):
+            raise ValueError("uavx: the state dict was taken from a batch of another shape")
+        snap = sd["snapshot"].to(self.device)
+        if snap.data_ptr() % 256:
+            blob = torch.empty((snap.numel() + 256,), dtype=torch.uint8, device=self.device)
+            off = (-blob.data_ptr()) % 256
+            blob[off:off + snap.numel()].copy_(snap)
+            snap = blob[off:off + snap.numel()]
+        _lib.check(self._L.uavx_load(self._h, snap.data_ptr(), self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()      # `snap` may be a temporary
+        self.seed, self.env_offset = int(host["seed"]), int(host["env_offset"])
+        self.levels = host["levels"]
+        if host.get("body_rule"):
+            self.body_rule = dict(host["body_rule"])
+        self._adopt_world(**host["world"])
+
     def metrics(self):
         """[E, 4] int32: steps, target_reach_count, collision_count, episode index (MUW:166-168)."""
         c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)

@@ -1783,6 +1783,7 @@ struct uavx_handle {
     MultiParams p;
     int device;
     void *slab;  // one allocation holding every state array
+    size_t slab_bytes = 0;
     // float64-position mode (uavx_set_position_mode): arrays allocated on first use
     bool wide = false;
     WideState w = {};
@@ -2157,6 +2158,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_stag = off;   off = align_up(off + 2 * E * sizeof(uint4), 256);
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
+    h->slab_bytes = off;
     e = hipMemset(h->slab, 0, off);
     if (e != hipSuccess) { (void)hipFree(h->slab); delete h; return UAVX_ERR_HIP; }
     char *b = static_cast<char *>(h->slab);
@@ -2548,6 +2550,90 @@ int uavx_get_state_f64(uavx_handle *h, const uavx_state_view_f64 *dst, void *str
     uavx_state_view none;
     std::memset(&none, 0, sizeof none);
     return wide_exchange(h, none, *dst, 0, static_cast<hipStream_t>(stream));
+}
+
+// ---- exact snapshot / restore of a handle (checkpoint row) ----
+namespace {
+constexpr uint64_t kSnapMagic = 0x3358564155ull;   // "UAVX3"
+struct SnapHeader {
+    uint64_t magic;
+    uint32_t version, header_bytes;
+    uint64_t slab_bytes, wide_bytes;
+    int64_t E, env_offset;
+    int32_t N, B, wide, ext, n_levels, level_lo, level_hi, prefetch_every;
+    uint32_t world_version, pad;
+    uavx_config cfg;
+    uavx_body_rule rule;
+    LevelTable levels;
+};
+size_t wide_slab_bytes(const uavx_handle *h) {   // the float64-position arrays (uavx_set_position_mode): 48 B per agent
+    const size_t A = (size_t)h->p.E * h->p.N;
+    return 2 * align_up(A * sizeof(double2), 256) + 2 * align_up(A * sizeof(double), 256);
+}
+size_t snap_header_bytes() { return align_up(sizeof(SnapHeader), 256); }
+__global__ void snap_header_kernel(SnapHeader *dst, SnapHeader hd) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = hd;
+}
+}  // namespace
+
+int64_t uavx_snapshot_bytes(const uavx_handle *h) {
+    if (!h) return -1;
+    return (int64_t)(snap_header_bytes() + h->slab_bytes + wide_slab_bytes(h));
+}
+
+int uavx_save(uavx_handle *h, void *dst, void *stream) {
+    if (!h || !dst) return UAVX_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(dst) & 255u) return fail(h, UAVX_ERR_INVALID_ARG, "uavx_save: the snapshot buffer must be 256-byte aligned");
+    UAVX_ENTER(h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SnapHeader hd;
+    std::memset(&hd, 0, sizeof hd);
+    hd.magic = kSnapMagic; hd.version = UAVX_VERSION; hd.header_bytes = (uint32_t)snap_header_bytes();
+    hd.slab_bytes = h->slab_bytes; hd.wide_bytes = h->wide ? wide_slab_bytes(h) : 0;
+    hd.E = h->p.E; hd.env_offset = h->p.env_offset; hd.N = h->p.N; hd.B = h->p.B; hd.wide = h->wide ? 1 : 0; hd.ext = h->ext ? 1 : 0;
+    hd.n_levels = h->p.n_levels; hd.level_lo = h->p.level_lo; hd.level_hi = h->p.level_hi; hd.prefetch_every = h->prefetch_every;
+    hd.world_version = h->p.world_version;
+    hd.cfg = h->cfg; hd.rule = h->rule; hd.levels = h->levels;
+    char *b = static_cast<char *>(dst);
+    hipLaunchKernelGGL(snap_header_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<SnapHeader *>(b), hd);   // (by value: no host buffer to keep alive)
+    UAVX_HIP(h, hipGetLastError());
+    UAVX_HIP(h, hipMemcpyAsync(b + hd.header_bytes, h->slab, h->slab_bytes, hipMemcpyDeviceToDevice, st));
+    if (h->wide) UAVX_HIP(h, hipMemcpyAsync(b + hd.header_bytes + h->slab_bytes, h->wide_slab, hd.wide_bytes, hipMemcpyDeviceToDevice, st));
+    return UAVX_OK;
+}
+
+int uavx_load(uavx_handle *h, const void *src, void *stream) {
+    if (!h || !src) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SnapHeader hd;
+    UAVX_HIP(h, hipMemcpyAsync(&hd, src, sizeof hd, hipMemcpyDeviceToHost, st));
+    UAVX_HIP(h, hipStreamSynchronize(st));   // the header decides what follows: this call waits for `stream`
+    if (hd.magic != kSnapMagic || hd.version != UAVX_VERSION || hd.header_bytes != snap_header_bytes())
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: not a snapshot of this library version");
+    if (hd.E != h->p.E || hd.N != h->p.N || hd.B != h->p.B || hd.slab_bytes != h->slab_bytes)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: the snapshot was taken from a handle of another shape (envs / agents / bodies)");
+    const char *b = static_cast<const char *>(src);
+    if (hd.wide) {   // the float64-position arrays exist from the first switch to that mode on
+        const int rc = uavx_set_position_mode(h, UAVX_POS_F64, stream);
+        if (rc != UAVX_OK) return rc;
+    }
+    UAVX_HIP(h, hipMemcpyAsync(h->slab, b + hd.header_bytes, h->slab_bytes, hipMemcpyDeviceToDevice, st));
+    if (hd.wide) UAVX_HIP(h, hipMemcpyAsync(h->wide_slab, b + hd.header_bytes + h->slab_bytes, hd.wide_bytes, hipMemcpyDeviceToDevice, st));
+    // host side of the handle: world, body rule, curriculum, staging cadence -- everything later launches take by value
+    h->cfg = hd.cfg;
+    derive_world_params(h->cfg, h->p);
+    h->wl = derive_wide_limits(h->cfg);
+    h->rule = hd.rule;
+    apply_body_rule(h);
+    h->levels = hd.levels;
+    h->p.n_levels = hd.n_levels; h->p.level_lo = hd.level_lo; h->p.level_hi = hd.level_hi;
+    h->p.world_version = hd.world_version;
+    h->p.env_offset = hd.env_offset;      // the snapshot brings its own global env ids (the Philox streams are keyed by them)
+    h->prefetch_every = hd.prefetch_every;
+    h->ext = hd.ext != 0;
+    h->wide = hd.wide != 0;
+    return UAVX_OK;
 }
 
 int uavx_get_metrics(uavx_handle *h, uint32_t *counters, void *stream) {

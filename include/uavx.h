@@ -311,6 +311,19 @@ int uavx_get_position_mode(const uavx_handle *h);
 int uavx_set_state_f64(uavx_handle *h, const uavx_state_view_f64 *src, void *stream);
 int uavx_get_state_f64(uavx_handle *h, const uavx_state_view_f64 *dst, void *stream);
 
+/* Exact snapshot / restore of everything a handle holds (the reference never checkpoints its env -- only the agents,
+ * sac.py:101-139 -- so a 65 536-env training run could not be resumed where it stopped): agent state, counters, running and
+ * ended-episode statistics, body records, levels, the parked layouts of the auto-reset and the host-side parameters later
+ * launches take by value (world, body rule, curriculum, staging cadence).  After uavx_load the handle continues bit for bit
+ * as the saved one would have (same outputs, same auto-reset draws, same uavx_get_episode_stats).
+ *   uavx_snapshot_bytes  size of the DEVICE buffer a snapshot needs (fixed for a handle).
+ *   uavx_save            enqueues the copy on `stream` (device to device; 256-byte aligned buffer); no synchronisation.
+ *   uavx_load            the handle must have the shape (envs, agents, bodies) the snapshot was taken from; reads the
+ *                        snapshot's header on the host first, so it WAITS for `stream` once, then enqueues the copy. */
+int64_t uavx_snapshot_bytes(const uavx_handle *h);
+int uavx_save(uavx_handle *h, void *snapshot, void *stream);
+int uavx_load(uavx_handle *h, const void *snapshot, void *stream);
+
 /* Episode metrics of MUW:166-168,209,221,238 as the trainers read them before reset
  * (test_sac_multi.py:164-165): counters [E*4] uint32 = steps, target_reach_count,
  * collision_count, episode index. */

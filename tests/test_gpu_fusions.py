@@ -150,6 +150,62 @@ def test_flags_packed_into_the_done_byte_vs_oracle(amd, oracle_mod, n, bodies, p
     env.close(); twin.close()
 
 
+@pytest.mark.parametrize("n,bodies", [(4, 0), (8, 16)])
+def test_snapshot_restores_a_running_batch_exactly(amd, n, bodies, tmp_path):
+    """uavx_save / uavx_load: 100 fused steps (auto-reset, statistics, curriculum, bodies) -> save -> 50 steps -> load -> the
+    same 50 steps again: every output of every step and episode_stats() identical; the snapshot also restores a FRESH handle
+    (through torch.save / torch.load of the state dict), which then produces the same 50 steps."""
+    import torch
+    E = 4096
+    kw = dict(num_agents=n, x_size=24.0, y_size=24.0, d_sense=9.0, **(dict(num_bodies=bodies, body_period=8, body_seed=4) if bodies else {}))
+    levels = [dict(x_size=18.0, y_size=18.0, collider_radius=0.5, d_sense=7.0, n_active=max(1, n // 2), b_active=bodies // 2),
+              dict(x_size=24.0, y_size=24.0, collider_radius=1.0, d_sense=9.0, n_active=n, b_active=bodies)]
+    g = torch.Generator(device="cpu").manual_seed(2)
+    tape = torch.rand((150, E, n, 2), generator=g) * 2 - 1
+    step_kw = dict(polar=True, auto_reset="agent0_done", step_cap=23, track_returns=True)
+
+    def run(env, lo, hi):
+        outs = []
+        for t in range(lo, hi):
+            o, r, d, info = env.step_ex(tape[t].to(env.device), **step_kw)
+            outs.append((o.clone(), r.clone(), d.clone(), info["reset_mask"].clone(), info["ended"].clone(), info["truncated"].clone()))
+        return outs
+
+    env = amd.BatchedMultiUAVWorld2D(E, seed=17, env_offset=9, **kw)
+    env.set_curriculum(levels, lo=0, hi=1)
+    env.reset()
+    run(env, 0, 100)
+    sd = env.state_dict()
+    torch.save(sd, tmp_path / "env.pt")
+    first = run(env, 100, 150)
+    stats_first = {k: v.clone() for k, v in env.episode_stats().items()}
+    env.set_level_window(1, 1)                      # wander off: another world version, other statistics
+    run(env, 0, 7)
+    env.load_state_dict(sd)
+    again = run(env, 100, 150)
+    for a, b in zip(first, again):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    for k, v in env.episode_stats().items():
+        assert torch.equal(v, stats_first[k]), k
+    state_first = {k: v.clone() for k, v in env.get_state().items()}
+    env.close()
+    fresh = amd.BatchedMultiUAVWorld2D(E, seed=0, env_offset=0, **kw)     # another seed / offset: the snapshot brings its own
+    fresh.load_state_dict(torch.load(tmp_path / "env.pt", weights_only=True))
+    third = run(fresh, 100, 150)
+    for a, b in zip(first, third):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    for k, v in fresh.episode_stats().items():
+        assert torch.equal(v, stats_first[k]), k
+    for k, v in fresh.get_state().items():
+        assert torch.equal(v, state_first[k]), k
+    small = amd.BatchedMultiUAVWorld2D(E // 2, **kw)
+    with pytest.raises(ValueError):
+        small.load_state_dict(sd)
+    fresh.close(); small.close()
+
+
 def test_curriculum_set_config_between_launches_vs_oracle(amd, oracle_mod):
     """uavx_set_config: world scalars change between launches (box shrinks, sensing range / collider / speed
     limits move); the same schedule on the oracle gives the same masks, states and reset streams."""
