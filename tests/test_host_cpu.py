@@ -248,6 +248,67 @@ def test_checkpoint_written_in_the_reference_layout(tmp_path):
         assert torch.equal(a, b)
 
 
+def test_td3_and_ddpg_checkpoint_layouts_on_cpu(tmp_path):
+    """The batched actors mirror the parameter names of the reference's TD3 Actor (td3.py:14-27) and DDPG ActorNetwork
+    (model.py:6-31, incl. its unused BatchNorm1d buffers), load what the reference writes (weights_only=True), and write files
+    with exactly the reference's keys whose entries load into reference-shaped modules and optimisers."""
+    from gym_uav_collision_avoidance_amd import policy as P
+    torch.manual_seed(3)
+    # --- TD3: a checkpoint in the reference's layout (td3.py:163-169) -> loader -> batched act
+    src = P.TD3Actor()
+    assert set(src.state_dict()) == {f"l{i}.{w}" for i in (1, 2, 3) for w in ("weight", "bias")}
+    assert src.l1.weight.shape == (256, 10) and src.l3.weight.shape == (2, 256)
+    f = tmp_path / "td3" / "weights.chpt"
+    f.parent.mkdir()
+    torch.save({"actor_state_dict": src.state_dict(), "actor_target_state_dict": src.state_dict(), "critic_state_dict": {},
+                "critic_target_state_dict": {}, "actor_optimizer_state_dict": {}, "critic_optimizer_state_dict": {}}, f)
+    pol = P.load_td3_checkpoint(str(f), device="cpu")
+    obs = torch.rand((6, 3, 10))
+    a = pol.act(obs)
+    assert a.shape == (6, 3, 2) and float(a.abs().max()) <= 1.0 and torch.equal(a, src(obs))
+    g = torch.Generator().manual_seed(0)
+    noisy = pol.act(obs, evaluate=False, generator=g)
+    assert not torch.equal(noisy, a) and float(noisy.abs().max()) <= 1.0
+    out = P.save_td3_checkpoint(str(tmp_path / "td3_out" / "weights.chpt"), pol)
+    ck = torch.load(out, weights_only=True)
+    assert tuple(ck) == P.TD3_CHECKPOINT_KEYS
+    assert set(ck["critic_state_dict"]) == {f"l{i}.{w}" for i in range(1, 7) for w in ("weight", "bias")} and ck["critic_state_dict"]["l4.weight"].shape == (256, 12)
+    a2, q2 = P.TD3Actor(), P.TD3TwinQ()                                   # what TD3.load_checkpoint does (td3.py:176-182)
+    a2.load_state_dict(ck["actor_state_dict"]); a2.load_state_dict(ck["actor_target_state_dict"])
+    q2.load_state_dict(ck["critic_state_dict"]); q2.load_state_dict(ck["critic_target_state_dict"])
+    torch.optim.Adam(a2.parameters(), lr=3e-4).load_state_dict(ck["actor_optimizer_state_dict"])
+    torch.optim.Adam(q2.parameters(), lr=3e-4).load_state_dict(ck["critic_optimizer_state_dict"])
+    assert torch.equal(a2(obs), a)
+    # --- DDPG: actor.chpt / critic.chpt (ddpg.py:124-135)
+    dsrc = P.DDPGActor()
+    assert set(dsrc.state_dict()) == {"input.weight", "input.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                                      "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked"}
+    assert dsrc.input.weight.shape == (400, 10) and dsrc.fc1.weight.shape == (300, 400) and dsrc.fc2.weight.shape == (2, 300)
+    d = tmp_path / "ddpg"
+    d.mkdir()
+    torch.save({"model_state_dict": dsrc.state_dict(), "target_model_state_dict": dsrc.state_dict(), "optimizer_state_dict": {}}, d / "actor.chpt")
+    dpol = P.load_ddpg_checkpoint(str(d), device="cpu")
+    da = dpol.act(obs)
+    assert da.shape == (6, 3, 2) and torch.equal(da, dsrc.eval()(obs))
+    want = torch.tanh(dsrc.fc2(torch.nn.functional.leaky_relu(dsrc.fc1(torch.nn.functional.leaky_relu(dsrc.input(obs))))))   # model.py:23-31, bn1 unused
+    assert torch.allclose(da, want)
+    assert torch.equal(dpol.act(obs, evaluate=False, noise=torch.full((2,), 5.0)), torch.ones_like(da))     # OU noise added, clipped
+    outd = P.save_ddpg_checkpoint(str(tmp_path / "ddpg_out"), dpol)
+    for name, mod in (("actor.chpt", P.DDPGActor()), ("critic.chpt", P.DDPGCritic())):
+        ck = torch.load(os.path.join(outd, name), weights_only=True)
+        assert tuple(ck) == P.DDPG_CHECKPOINT_KEYS
+        mod.load_state_dict(ck["model_state_dict"]); mod.load_state_dict(ck["target_model_state_dict"])
+        torch.optim.Adam(mod.parameters(), lr=1e-3, amsgrad=True).load_state_dict(ck["optimizer_state_dict"])
+    # --- the three layouts told apart by their keys
+    sac = P.GaussianPolicy()
+    torch.save({"policy_state_dict": sac.state_dict()}, tmp_path / "sac.chpt")
+    assert isinstance(P.load_actor(str(tmp_path / "sac.chpt"), device="cpu"), P.GaussianPolicy)
+    assert isinstance(P.load_actor(str(f), device="cpu"), P.TD3Actor) and isinstance(P.load_actor(str(d), device="cpu"), P.DDPGActor)
+    torch.save({"something": 1}, tmp_path / "x.chpt")
+    with pytest.raises(ValueError):
+        P.load_actor(str(tmp_path / "x.chpt"), device="cpu")
+
+
 def test_bench_algorithmic_bytes_and_refusal_without_gpu():
     """The per-env-step byte figures bench.py prices the roofline with and its refusal to run without a GPU."""
     import subprocess
