@@ -23,7 +23,7 @@ SYMBOLS = (
     "uavx_num_agents", "uavx_set_config", "uavx_set_body_rule", "uavx_num_bodies", "uavx_get_bodies", "uavx_set_bodies",
     "uavx_set_curriculum", "uavx_set_env_levels", "uavx_get_env_levels", "uavx_set_prefetch", "uavx_reset", "uavx_step", "uavx_step_k", "uavx_observe", "uavx_get_state",
     "uavx_set_state", "uavx_set_position_mode", "uavx_get_position_mode", "uavx_set_state_f64", "uavx_get_state_f64",
-    "uavx_get_metrics", "uavx_snapshot_bytes", "uavx_save", "uavx_load", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
+    "uavx_get_metrics", "uavx_get_nonfinite", "uavx_snapshot_bytes", "uavx_save", "uavx_load", "uavx_step_ex", "uavx_get_episode_stats", "uavx_clear_episode_stats",
     "uavx_uw_create", "uavx_uw_destroy", "uavx_uw_last_error",
     "uavx_uw_reset", "uavx_uw_step", "uavx_uw_observe", "uavx_uw_get_state", "uavx_uw_set_state",
     "uavx_uw_step_ex", "uavx_uw_get_episode_stats", "uavx_uw_clear_episode_stats",
@@ -204,6 +204,7 @@ def load():
     L.uavx_set_state_f64.argtypes = [vp, ctypes.POINTER(StateViewF64), vp]
     L.uavx_get_state_f64.argtypes = [vp, ctypes.POINTER(StateViewF64), vp]
     L.uavx_get_metrics.argtypes = [vp, vp, vp]
+    L.uavx_get_nonfinite.argtypes = [vp, vp, vp]
     L.uavx_snapshot_bytes.argtypes = [vp]
     L.uavx_snapshot_bytes.restype = i64
     L.uavx_save.argtypes = [vp, vp, vp]

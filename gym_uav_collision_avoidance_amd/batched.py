@@ -104,9 +104,10 @@ class HipArrayAdapter:
 class BatchedMultiUAVWorld2D(_Base):
     """E x MultiUAVWorld2D (MUW:10).  Constructor keywords match MUW:13.
 
-    step()/reset() return views of internal HBM buffers; observations are double-buffered so the
-    previous step's `obs` stays valid while the next one is produced (replay tuples (s, a, r, s'),
-    test_sac_multi.py:101-105)."""
+    step()/reset() return views of internal HBM buffers; observations, rewards and dones are double-buffered, so
+    what step t returned stays valid while step t+1 is produced (replay tuples (s, a, r, s'), test_sac_multi.py:101-105;
+    n-step / GAE collectors that hold r_t across the next step) and is overwritten by step t+2: clone what must live
+    longer, or hand in your own buffers (`out=`, DeviceReplay)."""
 
     def __init__(self, num_envs, x_size=50.0, y_size=50.0, max_speed=10.0, max_acceleration=5.0, num_agents=4,
                  collider_radius=1.0, d_sense=15, device=None, env_offset=0, seed=0, num_bodies=0, body_speed=5.0,
@@ -131,16 +132,17 @@ class BatchedMultiUAVWorld2D(_Base):
         E, N = self.num_envs, self.num_agents
         with torch.cuda.device(self.device):
             self._obs = [torch.zeros((E, N, _lib.OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
-            self._rew = torch.zeros((E, N), dtype=torch.float32, device=self.device)
-            self._done = torch.zeros((E, N), dtype=torch.uint8, device=self.device)
+            self._rews = [torch.zeros((E, N), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._dones = [torch.zeros((E, N), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self._rew, self._done = self._rews[0], self._dones[0]     # (shape / dtype templates for the out= checks)
         self._flip = 0
         self._resets = 0
         # hot-path caches: eager stepping is host-bound (a launch is ~6.6 us of GPU time at 65 536 x 4), so the
         # per-call Python work is kept to a pointer fetch, one shape/dtype test and the ctypes call
         self._act_shape = torch.Size((E, N, 2))
         self._obs_ptr = [o.data_ptr() for o in self._obs]
-        self._rew_ptr, self._done_ptr = self._rew.data_ptr(), self._done.data_ptr()
-        self._done_bool = self._done.view(torch.bool)
+        self._rew_ptr, self._done_ptr = [r.data_ptr() for r in self._rews], [d.data_ptr() for d in self._dones]
+        self._done_bools = [d.view(torch.bool) for d in self._dones]
         self._step_fn = self._L.uavx_step
         self._info = {"distance": 0}
 
@@ -303,14 +305,16 @@ class BatchedMultiUAVWorld2D(_Base):
         if (out is None and type(actions) is torch.Tensor and actions.dtype is torch.float32
                 and actions.shape == self._act_shape and actions.is_contiguous() and actions.device == self.device):
             self._flip ^= 1  # fast path: device float32 tensor of the right shape, internal output buffers
-            rc = self._step_fn(self._h, actions.data_ptr(), _lib.F32, 1 if evaluate else 0, self._obs_ptr[self._flip],
-                               self._rew_ptr, self._done_ptr, self._stream())
+            f = self._flip
+            rc = self._step_fn(self._h, actions.data_ptr(), _lib.F32, 1 if evaluate else 0, self._obs_ptr[f],
+                               self._rew_ptr[f], self._done_ptr[f], self._stream())
             if rc:
                 _lib.check(rc, self._h)
-            return self._obs[self._flip], self._rew, self._done_bool, self._info
+            return self._obs[f], self._rews[f], self._done_bools[f], self._info
         a, code = self._actions_arg(actions, (self.num_envs, self.num_agents, 2))
         if out is None:
-            obs, rew, done = self._next_obs_buf(), self._rew, self._done
+            obs = self._next_obs_buf()
+            rew, done = self._rews[self._flip], self._dones[self._flip]
         else:
             obs = self._out(out[0], self._obs[0].shape, torch.float32, "out[0]")
             rew = self._out(out[1], self._rew.shape, torch.float32, "out[1]")
@@ -350,8 +354,9 @@ class BatchedMultiUAVWorld2D(_Base):
             a, code = self._actions_arg(actions, (self.num_envs, self.num_agents, 2))
         if out is None:
             self._flip ^= 1
-            obs, rew, done, done_bool = self._obs[self._flip], self._rew, self._done, self._done_bool
-            obs_ptr, rew_ptr, done_ptr = self._obs_ptr[self._flip], self._rew_ptr, self._done_ptr
+            f = self._flip
+            obs, rew, done, done_bool = self._obs[f], self._rews[f], self._dones[f], self._done_bools[f]
+            obs_ptr, rew_ptr, done_ptr = self._obs_ptr[f], self._rew_ptr[f], self._done_ptr[f]
         else:  # caller-owned output buffers (DeviceReplay): same shape / dtype / device / contiguity checks as step()
             obs = self._out(out[0], self._obs[0].shape, torch.float32, "out[0]")
             rew = self._out(out[1], self._rew.shape, torch.float32, "out[1]")
@@ -436,7 +441,8 @@ class BatchedMultiUAVWorld2D(_Base):
             rew = torch.empty((K, E, N), dtype=torch.float32, device=self.device)
             done = torch.empty((K, E, N), dtype=torch.uint8, device=self.device)
         else:
-            obs, rew, done = self._next_obs_buf(), self._rew, self._done
+            obs = self._next_obs_buf()
+            rew, done = self._rews[self._flip], self._dones[self._flip]
         _lib.check(self._L.uavx_step_k(self._h, K, a.data_ptr(), code, int(bool(evaluate)), int(bool(tape_out)),
                                        obs.data_ptr(), rew.data_ptr(), done.data_ptr(), self._stream()), self._h)
         return obs, rew, done.view(torch.bool), {"distance": 0}
@@ -566,6 +572,14 @@ class BatchedMultiUAVWorld2D(_Base):
         _lib.check(self._L.uavx_get_metrics(self._h, c.data_ptr(), self._stream()), self._h)
         return c
 
+    def nonfinite_count(self):
+        """[E] int32: agent-steps of each env's running episode whose reward came out NaN / Inf (a poisoned command or
+        state; cleared at reset).  `bool(env.nonfinite_count().any())` is the batched form of the trainers' NaN tripwire
+        (test_ddpg_multi.py:114-130)."""
+        c = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.uavx_get_nonfinite(self._h, c.data_ptr(), self._stream()), self._h)
+        return c
+
     @property
     def steps(self):
         return self.metrics()[:, 0]
@@ -607,9 +621,10 @@ class BatchedUAVWorld2D(_Base):
         E = self.num_envs
         with torch.cuda.device(self.device):
             self._obs = [torch.zeros((E, _lib.UW_OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
-            self._rew = torch.zeros((E,), dtype=torch.float32, device=self.device)
-            self._done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
-            self._info = torch.zeros((E,), dtype=torch.float32, device=self.device)
+            # double-buffered like the observations: what step t returned is overwritten by step t + 2
+            self._rews = [torch.zeros((E,), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._dones = [torch.zeros((E,), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self._infos = [torch.zeros((E,), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._flip = 0
 
     def close(self):
@@ -644,9 +659,10 @@ class BatchedUAVWorld2D(_Base):
     def step(self, actions):  # UW:137-173
         a, code = self._actions_arg(actions, (self.num_envs, 2))
         obs = self._next_obs_buf()
-        _lib.check(self._L.uavx_uw_step(self._h, a.data_ptr(), code, obs.data_ptr(), self._rew.data_ptr(),
-                                        self._done.data_ptr(), self._info.data_ptr(), self._stream()), self._h, uw=True)
-        return obs, self._rew, self._done.view(torch.bool), {"distance": self._info}
+        rew, done, info = self._rews[self._flip], self._dones[self._flip], self._infos[self._flip]
+        _lib.check(self._L.uavx_uw_step(self._h, a.data_ptr(), code, obs.data_ptr(), rew.data_ptr(),
+                                        done.data_ptr(), info.data_ptr(), self._stream()), self._h, uw=True)
+        return obs, rew, done.view(torch.bool), {"distance": info}
 
     def step_ex(self, actions, polar=False, auto_reset=False, step_cap=0, track_returns=True):
         """env.step plus the single-agent trainer loop's bookkeeping (test_sac.py:77-80,98,106-109): polar=True
@@ -658,14 +674,14 @@ class BatchedUAVWorld2D(_Base):
         if not hasattr(self, "_reset_mask"):
             self._reset_mask = torch.zeros((3, self.num_envs), dtype=torch.uint8, device=self.device)
         m = self._reset_mask
+        rew, done, info = self._rews[self._flip], self._dones[self._flip], self._infos[self._flip]
         args = _lib.UWStepArgs(a.data_ptr(), code, _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN,
                                int(bool(auto_reset)), int(step_cap), int(bool(track_returns)), 0, self.seed,
-                               obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(), self._info.data_ptr(),
+                               obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr(),
                                m[0].data_ptr(), m[1].data_ptr(), m[2].data_ptr())
         _lib.check(self._L.uavx_uw_step_ex(self._h, ctypes.byref(args), self._stream()), self._h, uw=True)
         mb = m.view(torch.bool)
-        return obs, self._rew, self._done.view(torch.bool), {"distance": self._info, "reset_mask": mb[0], "ended": mb[1],
-                                                             "truncated": mb[2]}
+        return obs, rew, done.view(torch.bool), {"distance": info, "reset_mask": mb[0], "ended": mb[1], "truncated": mb[2]}
 
     def episode_stats(self):
         c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)

@@ -67,6 +67,14 @@ struct WorldLims {
     float sq_sense, sq_two_r, inv_sense, inv_diag;
 };
 
+// The kernels take this struct BY VALUE: it is their kernel-argument segment, fetched by scalar loads at the top of every
+// wavefront, and a 65 536 x 4 step launch is latency-shaped -- so the ORDER of the members is a tuning
+// parameter, and not an intuitive one.  Measured on one box (profiles/r03_ab_notes.md): a new pointer inserted after `coll`
+// cost the headline launch 0.35 us of 5.72 with NO other change to the kernel (the members behind it moved across the
+// scalar-load groups the compiler forms, nine loads instead of six sat in front of the first wait); the same pointer appended
+// at the end costs nothing beyond its own use (5.78 with the tripwire it serves); a deliberate "hot members first, one
+// 64-byte line per phase" order was WORSE at 4 UAVs (5.93) and better with scripted bodies (16.9 vs 17.4); parameters read
+// from a device-resident block instead (one pointer in the kernel arguments) gave 5.78 / 17.7.  New members go at the END.
 struct MultiParams {
     double tau, rtau, amax, vmax;  // rtau = RN(1/tau), see div_tau()
     double lox, loy, hix, hiy;
@@ -127,6 +135,10 @@ struct MultiParams {
     uint4 *stage_tag;             // [2][E] {episode index, seed lo, seed hi, level | world version << 8 | valid << 31}
     int magic_s;                  // 65536 / (L + B) + 1: thread / (L + B) of a staging workgroup by multiply-shift
     uint32_t world_version;       // bumped by every call that changes what a layout depends on (config, curriculum, body rule)
+    // agent-steps of the running episode whose reward came out non-finite (uavx_get_nonfinite): a NaN command or state
+    // poisons an agent for good (AG:26-27 lets it through), and at 65 536 envs nobody scans the observations for it.
+    // (LAST on purpose, see the note above the struct.)
+    uint32_t *nonfin;
 };
 constexpr uint32_t kStageValid = 0x80000000u;
 constexpr uint32_t kRecEnded = 0x80000000u;  // env_rec.y bit 31: episode ended, re-initialise at the next step_ex
@@ -790,6 +802,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void s
         done_out[m.a] = (uint8_t)dn;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
+        if (!(fabsf(rew) < INFINITY)) atomicAdd(&p.nonfin[m.e], 1u);   // the tripwire of test_ddpg_multi.py:114-130, per env
         if (m.lane == 0) {
             if (EXT) p.wave_steps[m.wave] = wave_count + 1u;   // single writer: this wave (MUW:238)
             else atomicAdd(&p.wave_steps[m.wave], 1u);         // MUW:238 for every env of this wave (no-return)
@@ -1029,6 +1042,7 @@ __device__ __forceinline__ void fold_store(const MultiParams &p, uint32_t e, uin
         p.fin_returns[e] = v.f;
     }
     p.reach[e] = 0; p.coll[e] = 0;  // MUW:167-168
+    p.nonfin[e] = 0;
 }
 
 // test_sac_multi.py:77-80 in float32: a in [-1,1]^2 -> velocity command.
@@ -1452,9 +1466,13 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         if (hit) {
             s.x = st.x; s.y = st.y; s.tx = st.z; s.ty = st.w;
             s.vx = 0.0; s.vy = 0.0; s.flags = 0;                 // MUW:120-123
+            // whether the learner is parked is read off the layout itself (a parked learner is staged at +inf), not off the
+            // level table: a table rewritten since the layout was drawn (uavx_set_curriculum under a graph captured before
+            // it, whose launches still carry the old world version and so still accept the old layouts) then cannot produce a
+            // learner that takes part without a position
             bool parked = false;
             if (EXT) {
-                parked = p.n_levels > 0 && m.i >= p.levels[hit_lvl].n_active;
+                parked = st.x == INFINITY;
                 s.flags = (hit_lvl << kLevelShift) | (parked ? kFlagInactive : 0u);
             }
             s.init_d = s.prev_d = parked ? INFINITY : norm32(s.tx - s.x, s.ty - s.y);  // MUW:154-155
@@ -1514,6 +1532,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         done_out[m.a] = (uint8_t)dbyte;
         if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
         if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
+        if (!(fabsf(rew) < INFINITY)) atomicAdd(&p.nonfin[m.e], 1u);
         if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
         if (m.i == 0) {
             // With scripted bodies the env record is read AGAIN here by the one lane that rewrites it, instead of being
@@ -1564,7 +1583,7 @@ __global__ __launch_bounds__(kWave * W) void step_k_kernel(MultiParams p, const 
     if (m.active) load_agent(p, m.a, s);
     const uint32_t flags_in = s.flags;
     const size_t A = (size_t)p.E * N;
-    uint32_t reach_acc = 0, coll_acc = 0;
+    uint32_t reach_acc = 0, coll_acc = 0, nonfin_acc = 0;
     for (int k = 0; k < K; k++) {
         double ax = 0.0, ay = 0.0;
         const size_t abytes = (ACT64 ? 16 : 8) * A * k;
@@ -1574,6 +1593,7 @@ __global__ __launch_bounds__(kWave * W) void step_k_kernel(MultiParams p, const 
         step_agent<NT, false>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce);
         reach_acc += re;
         coll_acc += ce;
+        nonfin_acc += !(fabsf(rew) < INFINITY) ? 1u : 0u;
         if (tape_out || k == K - 1) {
             const size_t off = tape_out ? (size_t)k * A : 0;
             if (m.active) {
@@ -1589,6 +1609,7 @@ __global__ __launch_bounds__(kWave * W) void step_k_kernel(MultiParams p, const 
         store_agent(p, m.a, s, flags_in);
         if (reach_acc) atomicAdd(&p.reach[m.e], reach_acc);  // MUW:221
         if (coll_acc) atomicAdd(&p.coll[m.e], coll_acc);     // MUW:209
+        if (nonfin_acc) atomicAdd(&p.nonfin[m.e], nonfin_acc);
         if (m.lane == 0) atomicAdd(&p.wave_steps[m.wave], (uint32_t)K);  // MUW:238
     }
 }
@@ -2145,6 +2166,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_wsteps = off; off = align_up(off + ((E + p.epw - 1) / p.epw) * 4, 256);
     const size_t o_reach = off; off = align_up(off + E * 4, 256);
     const size_t o_coll = off;  off = align_up(off + E * 4, 256);
+    const size_t o_nonfin = off; off = align_up(off + E * 4, 256);
     const size_t o_finc = off;  off = align_up(off + E * sizeof(uint4), 256);
     const size_t o_finr = off;  off = align_up(off + E * sizeof(float2), 256);
     const size_t o_bpos = off;  off = align_up(off + E * (size_t)B * sizeof(float2), 256);
@@ -2170,6 +2192,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.wave_steps = reinterpret_cast<uint32_t *>(b + o_wsteps);
     p.reach = reinterpret_cast<uint32_t *>(b + o_reach);
     p.coll = reinterpret_cast<uint32_t *>(b + o_coll);
+    p.nonfin = reinterpret_cast<uint32_t *>(b + o_nonfin);
     p.fin_counts = reinterpret_cast<uint4 *>(b + o_finc);
     p.fin_returns = reinterpret_cast<float2 *>(b + o_finr);
     p.body_pos = reinterpret_cast<float2 *>(b + o_bpos);
@@ -2448,6 +2471,13 @@ extern "C" int uavx_debug_stamps(unsigned long long *host_out, unsigned int *n) 
     return 0;
 }
 #endif
+
+int uavx_get_nonfinite(uavx_handle *h, uint32_t *counts, void *stream) {
+    if (!h || !counts) return UAVX_ERR_INVALID_ARG;
+    UAVX_ENTER(h);
+    UAVX_HIP(h, hipMemcpyAsync(counts, h->p.nonfin, (size_t)h->p.E * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return UAVX_OK;
+}
 
 int uavx_get_episode_stats(uavx_handle *h, uint32_t *counts, float *returns, void *stream) {
     if (!h) return UAVX_ERR_INVALID_ARG;

@@ -68,7 +68,7 @@ class UAVWorld2D:
         obs, rew, done, info = b.step(self._act_dev[key])
         p = self._pack
         p[:16].view(torch.float32).copy_(obs[0]); p[16:20].view(torch.float32).copy_(rew)
-        p[20:24].view(torch.float32).copy_(info["distance"]); p[24:25].copy_(b._done)
+        p[20:24].view(torch.float32).copy_(info["distance"]); p[24:25].copy_(done.view(torch.uint8))
         self._host.copy_(p, non_blocking=True)
         torch.cuda.current_stream(b.device).synchronize()
         h = self._host_np

@@ -24,8 +24,10 @@ def gather_episode_metrics(local, dst=0, group=None, total_envs=None):
     Returns the concatenated [E_total, C] tensor on dst, None elsewhere.
 
     Shard sizes follow from the layout, not from communication: total_envs=None means every rank owns the same
-    number of rows (the weak-scaling layout of bench.py); total_envs=T means the contiguous split of shard_range(T,
-    world, rank), whose first T % world ranks own one extra row -- rows are then padded to the largest shard."""
+    number of rows (the weak-scaling layout of bench.py) -- the caller's promise: ranks with different row counts would
+    hang the collective; total_envs=T means the contiguous split of shard_range(T, world, rank), whose first T % world
+    ranks own one extra row -- rows are then padded to the largest shard (gather_evaluation_summary passes the T that
+    make_sharded_env recorded on the env)."""
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
@@ -87,11 +89,19 @@ def make_sharded_env(total_envs, device=None, group=None, seed=0, **env_kwargs):
     else:
         world, rank = 1, 0
     offset, count = shard_range(total_envs, world, rank)
-    return BatchedMultiUAVWorld2D(count, device=device, env_offset=offset, seed=seed, **env_kwargs)
+    env = BatchedMultiUAVWorld2D(count, device=device, env_offset=offset, seed=seed, **env_kwargs)
+    # the job's size travels with the shard: shard_range gives unequal shards when total_envs % world != 0, and the gather
+    # below must then be told (every rank derives every shard's size from it -- no size exchange, one collective)
+    env.total_envs = int(total_envs)
+    return env
 
 
 def gather_evaluation_summary(env, dst=0, group=None, total_envs=None):
-    """SR / CR / score over the ended episodes of ALL shards (one gather of [E_local, 6] rows)."""
+    """SR / CR / score over the ended episodes of ALL shards (one gather of [E_local, 6] rows).  total_envs defaults to
+    what make_sharded_env recorded on `env`; an env built by hand for an UNEQUAL split must pass it (ranks that disagree
+    about the row count of a gather hang the collective)."""
+    if total_envs is None:
+        total_envs = getattr(env, "total_envs", None)
     st = env.episode_stats()
     rows = torch.stack([st["episodes"].float(), st["steps"].float(), st["reach"].float(), st["coll"].float(),
                         st["return0"], st["score"]], dim=1)

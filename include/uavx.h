@@ -175,7 +175,13 @@ int uavx_set_bodies(uavx_handle *h, const float *records, void *stream);
  *   level_lo <  0: the level assigned to the env with uavx_set_env_levels (default 0).
  * The reference's analogue is building a new env object per world (test_sac_multi_score.py:31-37).  n_levels = 0 removes
  * the table (every env back on uavx_config; follow it with uavx_reset: learners a level had parked stay parked until their
- * env is re-initialised).  Enqueues one tiny launch on `stream`. */
+ * env is re-initialised).  Enqueues one tiny launch on `stream`.
+ * hipGraphs: the level table lives in device memory and is rewritten in place, while the window [level_lo, level_hi], the
+ * number of levels and the version that invalidates parked auto-reset layouts travel in the kernel arguments of each launch.
+ * A graph captured BEFORE this call therefore replays with the old window and version against the NEW table: its envs draw
+ * old-window levels and may still consume layouts parked for the old table (their positions lie in the old levels' boxes).
+ * Nothing faults, but it is not the curriculum that was asked for: re-capture graphs after uavx_set_curriculum (as after
+ * uavx_set_config and uavx_set_body_rule). */
 typedef struct {
     double x_size, y_size, collider_radius, d_sense;
     int32_t n_active, b_active;
@@ -310,6 +316,13 @@ int uavx_set_position_mode(uavx_handle *h, int mode, void *stream);
 int uavx_get_position_mode(const uavx_handle *h);
 int uavx_set_state_f64(uavx_handle *h, const uavx_state_view_f64 *src, void *stream);
 int uavx_get_state_f64(uavx_handle *h, const uavx_state_view_f64 *dst, void *stream);
+
+/* NaN / Inf tripwire.  np.clip lets a NaN command through (AG:26-27), and an agent whose velocity is NaN stays poisoned
+ * for the rest of its episode; the reference's trainers notice by printing the agents' state and quitting
+ * (test_ddpg_multi.py:114-130).  counts [E] uint32 = agent-steps of the env's RUNNING episode whose reward came out
+ * non-finite (cleared with the MUW:166-168 counters at every reset): `counts.any()` is the batched form of that tripwire,
+ * and the env index says whose command to look at.  One compare per agent-step on the step path, an atomic on the event. */
+int uavx_get_nonfinite(uavx_handle *h, uint32_t *counts, void *stream);
 
 /* Exact snapshot / restore of everything a handle holds (the reference never checkpoints its env -- only the agents,
  * sac.py:101-139 -- so a 65 536-env training run could not be resumed where it stopped): agent state, counters, running and

@@ -754,7 +754,12 @@ def test_nonfinite_actions_propagate_like_numpy(amd, oracle_mod):
         assert obs_err(_np(obs_g)[finite], obs_o[finite]) <= TOL
         assert float(np.abs(_np(rew_g)[finite] - rew_o[finite]).max()) <= TOL
         assert np.isnan(_np(obs_g)[~finite]).any(axis=-1).all() if (~finite).any() else True
+        bad_steps = bad_steps + (~np.isfinite(rew_o)).sum(axis=1) if t else (~np.isfinite(rew_o)).sum(axis=1)
+        np.testing.assert_array_equal(_np(env.nonfinite_count()), bad_steps, err_msg=f"tripwire, step {t}")
     assert np.isnan(orc.vel[3, 3]).any() and np.isnan(orc.vel[4, 0]).any() and np.isfinite(orc.vel[0, 1]).all()
+    assert bad_steps[3] == 4 and bad_steps[4] == 4 and bad_steps[:3].sum() == 0 and bad_steps[5:].sum() == 0   # envs 3, 4 from step 2 on
+    env.reset()
+    assert int(env.nonfinite_count().sum()) == 0                          # cleared with the MUW:166-168 counters
     env.close()
 
 

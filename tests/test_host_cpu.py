@@ -120,6 +120,53 @@ def _gather_worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
+def _summary_worker(rank, world, port, total, q):
+    """gather_evaluation_summary over an ODD total split by shard_range, the size taken from the env object the way
+    make_sharded_env records it (the env here is a stand-in with the three things the function reads)."""
+    import torch.distributed as dist
+    from gym_uav_collision_avoidance_amd.sharding import gather_evaluation_summary, shard_range
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    off, cnt = shard_range(total, world, rank)
+    rows = torch.arange(off, off + cnt)
+
+    class Shard:
+        num_agents = 4
+        total_envs = total                      # what make_sharded_env sets
+
+        def episode_stats(self):
+            return dict(episodes=torch.ones_like(rows), steps=rows * 2, reach=rows % 3, coll=rows % 2,
+                        return0=rows.float(), score=rows.float() * 0.5)
+    calls = []
+    orig = dist.gather
+    dist.gather = lambda *a, **k: (calls.append("gather"), orig(*a, **k))[1]
+    out = gather_evaluation_summary(Shard(), dst=0)
+    assert calls == ["gather"], calls
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_evaluation_summary_over_an_odd_total():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, total, world = _free_port(), 13, 2   # 7 + 6 rows: ranks hold different row counts
+    procs = [ctx.Process(target=_summary_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows = np.arange(total)
+    assert got["episodes"] == total and got["success_rate"] == pytest.approx((rows % 3).sum() / (4 * total))
+    assert got["collision_rate"] == pytest.approx((rows % 2).sum() / (4 * total)) and got["mean_steps"] == pytest.approx((rows * 2).sum() / total)
+    assert got["avg_score"] == pytest.approx((rows * 0.5).sum() / (4 * total))
+
+
 def test_gloo_world2_metrics_gather():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
