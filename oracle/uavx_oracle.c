@@ -270,7 +270,7 @@ static int gather_slots(const envx *x, const double *loc, const double *vel, dou
         const int j = x->L + b, on = b < x->nb;
         const float *r = x->body + UAVO_BODY_DIM * b;
         px[j] = on ? (double)r[0] : INFINITY; py[j] = on ? (double)r[1] : INFINITY;
-        if (vx) { vx[j] = cos((double)r[4]); vy[j] = sin((double)r[4]); }  /* a body's heading is the stored float32 angle */
+        if (vx) { vx[j] = (double)r[4]; vy[j] = 0.0; }  /* a body's heading is the stored float32 angle (slots >= L: see observe_agent) */
     }
     return x->L + x->B;
 }
@@ -330,7 +330,7 @@ static void observe_agent(const envx *x, const uavo_state *st, int64_t e, int i,
             /* MUW:77/87: float32 norm / python scalar d_sense -> float32 division */
             nd = f64pos ? dist[k] / cfg->d_sense : (double)((float)dist[k] / (float)cfg->d_sense);
             rel_theta = atan2(pos_sub(f64pos, py[j], py[i]), pos_sub(f64pos, px[j], px[i])); /* MUW:78/88 */
-            dir = atan2(nvy[j], nvx[j]);                                            /* MUW:82/92 */
+            dir = (j >= x->L) ? nvx[j] : atan2(nvy[j], nvx[j]);                     /* MUW:82/92; a body (slot >= L): its stored heading */
         } else {
             nd = 1.0;
             rel_theta = M_PI + theta;

@@ -7,7 +7,9 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>/dev/
 python bench.py --fused --no-cpu-baseline > $O/bench_cfg3_fused.log 2>/dev/null && echo cfg3f done
 python bench.py --agents 8 --bodies 16 > $O/bench_cfg5.log 2>/dev/null && echo cfg5 done
 python bench.py --agents 8 --bodies 16 --fused --no-cpu-baseline > $O/bench_cfg5_fused.log 2>/dev/null && echo cfg5f done
-python bench.py --cfg5 --no-cpu-baseline > $O/bench_cfg5_designed.log 2>/dev/null && echo cfg5d done
+python bench.py --cfg5 > $O/bench_cfg5_designed.log 2>/dev/null && echo cfg5d done
+python bench.py --cfg5 --packed-flags --no-cpu-baseline > $O/bench_cfg5_designed_packed.log 2>/dev/null && echo cfg5dp done
+python bench.py --fused --packed-flags --no-cpu-baseline > $O/bench_cfg3_fused_packed.log 2>/dev/null && echo cfg3fp done
 python bench.py --agents 24 --ring 8 --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_n24.log 2>/dev/null && echo n24 done
 tools/sweep.sh > $O/sweep.jsonl && echo sweep done
 tools/sweep_envs.sh > $O/env_sweep.jsonl && echo envsweep done
