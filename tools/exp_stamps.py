@@ -20,7 +20,10 @@ env.set_prefetch(int(os.environ.get("UAVX_PREFETCH", "16")))
 env.reset()
 L = _lib.load()
 buf = (ctypes.c_ulonglong * (8 * 16384))(); n = ctypes.c_uint(0)
-kw = dict(polar=True, track_returns=True, auto_reset="agent0_done", step_cap=1500)
+MODES = {"all": dict(polar=True, track_returns=True, auto_reset="agent0_done", step_cap=1500),
+         "plain": dict(track_returns=False), "polar_track": dict(polar=True, track_returns=True),
+         "cap": dict(polar=True, track_returns=True, step_cap=1500)}
+kw = MODES[os.environ.get("UAVX_STAMP_MODE", "all")]
 for k in range(400):
     env.step_ex(ring[k % R], **kw)
 L.uavx_debug_stamps(buf, ctypes.byref(n))
