@@ -240,9 +240,10 @@ class Stepper:
 
 def timed_regions(stepper, K, repeats, device, dist=None, events=False):
     """`repeats` regions of exactly K step launches, each bracketed by barrier + synchronize on both sides.  events=False:
-    wall-clock regions (nothing but the K launches between the two clock reads); events=True: the same regions bracketed by
-    HIP events on the launch stream instead (device time of the K steps; the two event records would otherwise sit inside
-    the wall-clock region).  Returns the per-region times of this rank (s or ms)."""
+    wall-clock regions (nothing but the K launches between the two clock reads): what `value` / `ms_per_step` come from.
+    events=True: device time of K step launches from HIP events on the launch stream, in regions of their own (the two event
+    records would otherwise sit inside the wall-clock region), each preceded by an untimed pass of the same K launches so that
+    the events bracket kernels, not the host's enqueue latency.  Returns the per-region times of this rank (s or ms)."""
     out = []
     for _ in range(repeats):
         torch.cuda.synchronize(device)
@@ -250,7 +251,13 @@ def timed_regions(stepper, K, repeats, device, dist=None, events=False):
             dist.barrier()
         torch.cuda.synchronize(device)
         if events:
+            # device time of K step launches: an untimed pass of the same K launches goes first and the two events and the
+            # timed pass are enqueued BEHIND it, while it runs, so the host's latency of enqueueing on an idle stream is not
+            # inside the bracket.  What a short region still holds beside its K kernels is the DEVICE-side start of a graph
+            # replay (~10 us per replay, measured: 20 x 5.8 us of kernels come out as 128 us) -- rocprofv3's per-kernel average
+            # does not contain it, which is why a 20-step run also reports roofline_steady (1000-step regions)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            stepper.run(K)
             ev0.record()
             stepper.run(K)
             ev1.record()
@@ -608,7 +615,7 @@ def main():
                            "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",
             "ms_per_step_incl_amortised_gather": elapsed * 1e3 / K + gather_s * 1e3 / 1500.0,
             "episode_metrics": summ,
-            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + len(devs)),
+            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + 2 * len(devs)),   # (event regions: an untimed pass + the timed one)
         }
         if args.world == "multi":
             rv = valu_roofline(kernel_name, shape, kernel_s)

@@ -52,10 +52,11 @@ def test_driver_sized_run_is_a_pure_graph_replay():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 1
-    assert d["steps_executed"] == 3 + 5 + 10 * 20    # capture warm-up + warm-up + 5 wall-clock and 5 device-time regions (counted before roofline_steady runs)
+    assert d["steps_executed"] == 3 + 5 + 15 * 20    # capture warm-up + warm-up + 5 wall-clock and 5 device-time regions (each an untimed + a timed pass; counted before roofline_steady runs)
     assert d["value"] > 7e9, d["value"]   # 20 x ~6.3 us of kernels + one graph launch; 9-10 G on a quiet box
     st = d["roofline_steady"]             # the same launches over 1000-step regions, next to the 20-step figure
-    assert st["steps"] == 1000 and st["frac"] >= 0.95 * d["roofline"]["frac"] and st["kernel_us"] > 3.0   # (5 % for box noise)
+    assert st["steps"] == 1000 and st["frac"] >= 0.93 * d["roofline"]["frac"] and st["kernel_us"] > 3.0   # (box noise; both are pure device time now)
+    assert d["roofline"]["kernel_us"] < 1e3 * d["ms_per_step"]   # the wall-clock region holds one graph-launch latency, the event region none
 
 
 def test_cfg5_as_designed_line():
@@ -84,7 +85,7 @@ def test_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["parallelism"] == "env-index shard x2"
     assert abs(d["value"] - 2 * 8192 * 200 / (d["ms_per_step"] * 200 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
     assert "cpu_baseline" not in d
-    assert d["steps_executed"] == 3 + 20 + 10 * 200       # capture warm-up + warm-up + 5 wall-clock and 5 device-time regions
+    assert d["steps_executed"] == 3 + 20 + 15 * 200       # capture warm-up + warm-up + 5 wall-clock and 5 device-time regions (an untimed + a timed pass each)
     assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"])   # ... on every env of both shards
 
 
@@ -118,4 +119,4 @@ def test_rccl_code_path_with_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["config"]["mode"] == "graph", (d["config"], out.stderr[-1500:])
-    assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"]) == 2023.0
+    assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"]) == 3023.0
