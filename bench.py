@@ -430,6 +430,9 @@ def main():
     ap.add_argument("--packed-flags", action="store_true",
                     help="with --fused: UAVX_FLAGS_IN_DONE (ABI v3): reset_mask / ended / truncated ride in bits 1..3 of every env's "
                          "first done byte instead of three one-byte-per-env arrays")
+    ap.add_argument("--prefetch", type=int, default=None,
+                    help="with --fused: uavx_set_prefetch cadence (one staging workgroup per this many env-workgroups; 0 = off); "
+                         "default: the handle's own")
     ap.add_argument("--cfg5", action="store_true",
                     help="BASELINE configs[4] as designed: --agents 8 --bodies 16 --fused --curriculum 4 --replay")
     ap.add_argument("--mode", choices=("graph", "launch"), default="graph",
@@ -511,6 +514,8 @@ def main():
                           f"on average over its {n} levels: {bytes_per_env_step:.0f} B per env-step instead of "
                           f"{algorithmic_bytes_per_env_step(N, B)})")
         if args.fused:
+            if args.prefetch is not None:
+                env.set_prefetch(args.prefetch)
             ring = torch.rand((args.ring, E, N, 2), generator=gen, device=device) * 2 - 1
             fused_kw = dict(polar=True, auto_reset="agent0_done", step_cap=1500, track_returns=True)
             if args.replay:

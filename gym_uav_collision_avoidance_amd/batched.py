@@ -215,10 +215,12 @@ class BatchedMultiUAVWorld2D(_Base):
         _lib.check(self._L.uavx_get_env_levels(self._h, t.data_ptr(), self._stream()), self._h)
         return t
 
-    def set_prefetch(self, every=16):
-        """Reset layouts drawn ahead of time (uavx_set_prefetch): every auto-resetting step_ex launch carries staging
-        workgroups that draw the next episodes' layouts for 1/`every` of the envs (rotating); 0 / False = off (every
-        auto-reset draws in place, inside its step workgroup).  Results do not depend on it."""
+    def set_prefetch(self, every):
+        """Reset layouts drawn ahead of time (uavx_set_prefetch): every auto-resetting step_ex launch carries one staging
+        workgroup per `every` env-workgroups; each looks at a window of envs and draws the missing layouts of their next
+        episodes.  0 / False = off (every auto-reset draws in place, inside its step workgroup).  The handle starts with a
+        cadence sized for num_envs / 64 layouts per launch (64 without scripted bodies, 16 with 8 learners + 16 bodies).
+        Results do not depend on it."""
         _lib.check(self._L.uavx_set_prefetch(self._h, int(every)), self._h)
 
     def get_bodies(self):

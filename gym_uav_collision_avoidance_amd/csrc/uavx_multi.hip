@@ -37,6 +37,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -146,6 +147,7 @@ constexpr uint32_t kFlagInactive = UAVX_FLAG_INACTIVE;
 constexpr int kLevelShift = 8;       // Goal::flags bits 8..11: the env's curriculum level (same value in every agent of the env)
 constexpr uint32_t kLevelMask = 0xFu << kLevelShift;
 constexpr int kExtSlots = 192;       // LDS neighbour rows per wave of an EXT kernel: epw * (L + B) <= 192
+constexpr int kHintJobs = 8;         // layouts a staging workgroup takes on per draw: its 8 hint slots are ONE 64-byte scalar load
 
 // options of uavx_step_ex that the kernel needs (uavx_step_args minus the buffers)
 struct StepExtra {
@@ -158,7 +160,9 @@ struct StepExtra {
     int use_stage;   // consult the pre-drawn layouts
     // layouts drawn ahead: the first pf_blocks workgroups of the launch do not step anything -- they draw the layouts of the
     // NEXT episodes of one slice of the envs (see stage_ahead); env-workgroup w is workgroup pf_blocks + w
-    uint32_t pf_blocks, pf_groups;   // leading workgroups, env-workgroups of the launch
+    uint32_t pf_blocks, pf_groups;   // staging workgroups, env-workgroups of the launch
+    uint32_t stage_first, step_first;   // block id of the first staging / first env-workgroup: (0, pf_blocks) or (pf_groups, 0)
+    uint2 *hints;                    // [pf_blocks][kHintJobs] {env + 1 (0: none), episode}: what a staging workgroup's last scan found
 };
 
 struct LaneMap {
@@ -1058,9 +1062,12 @@ __device__ __forceinline__ void polar_to_command(const MultiParams &p, float a0,
 // diagnostic build (tools/exp_stamps.py): every wavefront of a uavx_step_ex launch logs {start, mid, end, kind | xcc << 8 | block << 16}
 __device__ unsigned long long g_stamps[8 * 16384];
 __device__ unsigned int g_stamp_n;
-#define STAMP(k) do { stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
-__device__ __forceinline__ void stamp_log(const unsigned long long *st, unsigned int kind) {
+// (s_memtime counts per compute unit: differences inside one wavefront only; slot 6 carries the 100 MHz s_memrealtime of the
+//  wavefront's first and last stamp, low words, which IS one clock for the whole device: the launch's dispatch timeline)
+#define STAMP(k) do { stamps[k] = __builtin_amdgcn_s_memtime(); if ((k) == 0) stamps[6] = __builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull; } while (0)
+__device__ __forceinline__ void stamp_log(unsigned long long *st, unsigned int kind) {
     if ((threadIdx.x & 63) != 0) return;
+    st[6] |= (unsigned long long)__builtin_amdgcn_s_memrealtime() << 32;
     unsigned int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const unsigned int k = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;   // a slot per wavefront: no shared counter to queue on
@@ -1077,22 +1084,30 @@ __device__ __forceinline__ void stamp_log(const unsigned long long *st, unsigned
 // Layouts drawn ahead of time, inside the step launch.  The layout of an env's NEXT episode is a pure function of (seed,
 // global env, episode index, level rule); re-initialising an env from a parked layout costs 16-byte copies, drawing it in
 // place costs a serial accept / reject chain on ONE wavefront that the whole launch then waits for (with 16 scripted bodies:
-// 8 us for a lucky env running alone on its SIMD, 19 us for the unluckiest of the ~100 envs that reset in a launch).  So the
-// first pf_blocks workgroups of every auto-resetting uavx_step_ex launch draw instead of stepping.  A launch is as long as its
-// slowest wavefront, so what matters is how long ONE staging workgroup lives, not how many there are (per-wavefront
-// timelines: tools/exp_stamps.py, profiles/r03_ab_notes.md):
-//   * SCAN: a staging workgroup looks at one window of 64 W envs, a lane each (the window rotates with the handle's step
-//     count, a device-side counter: replays of a captured graph rotate like eager calls; at 65 536 envs the 512 staging
-//     workgroups of a launch cover half the batch): record and the tags of the env's two parked layouts, one memory round trip;
+// 8 us for a lucky env running alone on its SIMD, 19 us for the unluckiest of the ~100 envs that reset in a launch).  So
+// pf_blocks extra workgroups of every auto-resetting uavx_step_ex launch draw instead of stepping -- in front of the
+// env-workgroups or behind them (uavx_step_ex decides by the shape of the launch).  A launch is as long as its slowest
+// wavefront, so what matters is how long ONE staging workgroup lives and whom it keeps waiting, not how many there are
+// (per-wavefront timelines on the device-wide clock: tools/exp_stamps.py, profiles/r03_ab_notes.md):
+//   * a staging workgroup alternates between two short jobs.  SCAN (no hints left from its last launch): one window of 64 W
+//     envs, a lane each -- record and the tags of the env's two parked layouts, one memory round trip -- and the first few
+//     envs that miss a layout are written down as HINTS {env, episode} in the workgroup's own eight slots (no atomics, nobody
+//     else writes them); 2.5 us.  DRAW (the next launch finds the hints with one scalar load, a few hundred cycles): the
+//     hinted layouts are drawn at once.  Until this round one workgroup scanned AND drew in the same launch: 9 us with the
+//     chain waiting behind the scan's round trip at the most congested moment of the launch;
+//   * a hint is one launch old, so whether the layout is still wanted and whether its slot may be written NOW is decided from
+//     the env's record and the slot's tag as THIS launch finds them (the rule below) -- those two loads are requested before
+//     the Philox rounds and waited for in front of the stores, the whole chain runs under them on the hinted (env, episode),
+//     and a layout that fails the test is not stored.  Hints can be stale, lost or doubled: results never depend on them;
 //   * an env keeps TWO parked layouts, for its next episode (index y, slot y & 1) and the one after: consuming one leaves
-//     the other in place, so how soon a layout is parked again (two or three launches) is not critical and an env draws
-//     in place only at first use, after a changed seed / world, or when two of its episodes end within those few launches;
-//   * DRAW: the first floor(64 W / S) missing layouts the scan found are drawn at once with ONE LANE PER SLOT of the
-//     neighbour model (S = L + B lanes per layout, learners and bodies alike): every slot draws its candidate in the same
-//     Philox call and the chain is one fixed-point iteration over all start points followed by one over the learners'
-//     targets (round 2 mapped a lane per learner and walked the bodies in ceil(B / L) sequential trips, each with its own
-//     Philox calls and clash loops); what a window holds beyond that is found again when the window comes round (every
-//     other launch), so a full invalidation -- creation, a new seed or world -- is worked off at pf_blocks floor(64 W / S)
+//     the other in place, so how soon a layout is parked again (a few launches: window rotation + one for the hint) is not
+//     critical and an env draws in place only at first use, after a changed seed / world, or when two of its episodes end
+//     within those few launches;
+//   * DRAW maps ONE LANE PER SLOT of the neighbour model (S = L + B lanes per layout, learners and bodies alike; up to
+//     min(floor(64 W / S), 8) layouts per workgroup): every slot draws its candidates in the same fused Philox loop and the
+//     chain is one fixed-point iteration over all start points followed by one over the learners' targets (round 2 mapped a
+//     lane per learner and walked the bodies in ceil(B / L) sequential trips, each with its own Philox calls and clash loops).
+//     A full invalidation -- creation, a new seed or world -- is worked off at about pf_blocks / 2 workgroups' worth of
 //     layouts per launch while the envs that need one meanwhile draw in place as before (same result either way).
 // Safe against the step workgroups of the SAME launch: those read the staging arrays only of an env they re-initialise, i.e.
 // one whose record carried the "ended" mark when the launch began, and only slot y & 1 of it -- and exactly that slot of
@@ -1101,72 +1116,93 @@ __device__ __forceinline__ void stamp_log(const unsigned long long *st, unsigned
 // env_rec store, the last thing it does) only after every load it made from the staging arrays has returned -- the record's
 // new "ended" bit is computed from the step's done flags, which are computed from the loaded layout, so the store cannot be
 // issued earlier; a staging workgroup that sees the mark cleared (and the episode index moved on) may therefore overwrite
-// the consumed slot at once.  (tests/test_gpu_ext.py steps with caps of 1 and 2 and staging in every launch for that overlap.)
+// the consumed slot at once.  The rule does not care WHEN in the launch the record is read, which is what lets the staging
+// workgroups run behind the env-workgroups as well as in front of them.  (tests/test_gpu_ext.py steps with caps of 1 and 2
+// and staging in every launch for that overlap, on both positions.)
 struct StageMap {   // lane-per-slot mapping of a staging workgroup (the fields lowest_clash() reads are named as in LaneMap)
     int i, base, g, rbase;
     bool active;
     uint32_t e;
 };
 template <int NT, bool EXT, int W, class LDS>
-__device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtra &x, LDS &lds) {
+__device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtra &x, LDS &lds, uint32_t sb) {   // sb: which staging workgroup
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
 #endif
     const int L = NT ? NT : p.N;
     const int S = EXT ? p.nslots : L;                 // lanes per layout
-    const int epg = (kWave * W) / S;                  // layouts a staging workgroup draws
-    // ---- scan: one window of 64 W envs, a lane each ----
-    const uint32_t span = kWave * W;
-    const uint32_t windows = ((uint32_t)p.E + span - 1u) / span;
-    // Which window?  Staging workgroup b owns the windows b, b + pf_blocks, b + 2 pf_blocks ... and looks at one of them per
-    // launch, picked by the low bits of the clock: any window is as good as any other (results never depend on what is parked),
-    // and a rotation that counted launches would put a dependent memory round trip (the handle's step count lives in device
-    // memory, so that graph replays move on like eager calls) in front of the scan of EVERY staging workgroup -- which a
-    // displaced step workgroup is waiting behind.  With two parked layouts per env an env that has to wait a few launches
-    // longer for its turn loses nothing.
-    const uint32_t turns = (windows + x.pf_blocks - 1u) / x.pf_blocks;
-    const uint32_t turn = __builtin_amdgcn_readfirstlane((uint32_t)(__builtin_amdgcn_s_memtime() >> 7)) % turns;
-    const uint32_t se = ((blockIdx.x + turn * x.pf_blocks) % windows) * span + threadIdx.x;
-    uint32_t want_ep = 0;
-    bool need = false;
-    if (se < (uint32_t)p.E) {
-        const uint32_t y = p.env_rec[se].y;
-        const uint32_t ep = y & ~kRecEnded;
-        const uint4 t0 = p.stage_tag[se], t1 = p.stage_tag[(uint32_t)p.E + se];
-        const uint4 ta = (ep & 1u) ? t1 : t0, tb = (ep & 1u) ? t0 : t1;      // tags of the slots of episodes ep / ep + 1
-        const bool miss_a = !(y & kRecEnded) && !stage_hit(ta, stage_want<EXT>(p, se, ep, x.seed_lo, x.seed_hi));
-        const bool miss_b = !stage_hit(tb, stage_want<EXT>(p, se, (ep + 1u) & ~kRecEnded, x.seed_lo, x.seed_hi));
-        need = miss_a || miss_b;
-        want_ep = miss_a ? ep : ((ep + 1u) & ~kRecEnded);
-    }
-    // the level table (at most 16 x 80 B) rides the same round trip into LDS: the chain then reads its env's box from there
-    // instead of from memory (a dependent load behind the level draw)
-    // (16 levels x 5 float4 = 80 rows behind the 64 rows the chain of a one-wavefront workgroup works on; EXT kernels have 192)
-    constexpr int kLvlF4 = (int)(sizeof(LevelParams) / 16);
-    constexpr bool kLvlLds = EXT && W == 1 && LDS::kRows >= kWave + UAVX_MAX_LEVELS * kLvlF4;
-    if (kLvlLds && p.n_levels > 0) {
-#pragma unroll
-        for (int t = (int)threadIdx.x; t < UAVX_MAX_LEVELS * kLvlF4; t += kWave)
-            if (t < p.n_levels * kLvlF4) lds.pos[kWave + t] = reinterpret_cast<const float4 *>(p.levels)[t];
-    }
-    // the first epg of them become this workgroup's jobs (which ones does not matter)
+#ifdef UAVX_X_EPG1
+    const int epg = (S >= 16) ? 1 : min((kWave * W) / S, kHintJobs);
+#else
+    const int epg = min((kWave * W) / S, kHintJobs);    // layouts a staging workgroup draws at once
+#endif
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds.obs);        // job list: word 0 = count, job g = {env, episode} in words 1 + 2 g, 2 + 2 g
-    if (threadIdx.x == 0) cnt[0] = 0u;
-    group_sync<W>();
-    if (need) {
-        const uint32_t k = atomicAdd(cnt, 1u);
-        if ((int)k < epg) { cnt[1 + 2 * k] = se; cnt[2 + 2 * k] = want_ep; }
+    // ---- what did this workgroup's last scan find?  Its own hint slots, ONE scalar load (wave-uniform, through the scalar
+    // cache: a few hundred cycles at a moment when a vector load queues behind the first loads of every wavefront of the launch)
+    typedef uint32_t HintWords __attribute__((ext_vector_type(2 * kHintJobs)));
+    HintWords hw;
+    uint2 *myhints = x.hints + (size_t)sb * kHintJobs;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hw) : "s"(myhints) : "memory");
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < kHintJobs; k++) {      // uniform: scalar code, the list itself goes to LDS through lane 0
+        const uint32_t he = hw[2 * k], hp = hw[2 * k + 1];
+        if (k < epg && he != 0u && he <= (uint32_t)p.E) {
+            if (threadIdx.x == 0) { cnt[1 + 2 * n] = he - 1u; cnt[2 + 2 * n] = hp; }
+            n++;
+        }
     }
-    group_sync<W>();
-    const int n = min((int)cnt[0], epg);
     if (n == 0) {
+        // ---- scan: one window of 64 W envs, a lane each; what it finds is drawn by THIS workgroup in the NEXT launch ----
+        const uint32_t span = kWave * W;
+        const uint32_t windows = ((uint32_t)p.E + span - 1u) / span;
+        // Which window?  Staging workgroup b owns the windows b, b + pf_blocks, b + 2 pf_blocks ... and looks at one of them per
+        // launch, picked by the low bits of the clock: any window is as good as any other (results never depend on what is
+        // parked; nothing on the host or in device memory counts launches, so a captured graph behaves like eager calls).
+        const uint32_t turns = (windows + x.pf_blocks - 1u) / x.pf_blocks;
+        const uint32_t turn = __builtin_amdgcn_readfirstlane((uint32_t)(__builtin_amdgcn_s_memtime() >> 7)) % turns;
+        const uint32_t se = ((sb + turn * x.pf_blocks) % windows) * span + threadIdx.x;
+        uint32_t want_ep = 0;
+        bool need = false;
+        if (se < (uint32_t)p.E) {
+            const uint32_t y = p.env_rec[se].y;
+            const uint32_t ep = y & ~kRecEnded;
+            const uint4 t0 = p.stage_tag[se], t1 = p.stage_tag[(uint32_t)p.E + se];
+            const uint4 ta = (ep & 1u) ? t1 : t0, tb = (ep & 1u) ? t0 : t1;      // tags of the slots of episodes ep / ep + 1
+            const bool miss_a = !(y & kRecEnded) && !stage_hit(ta, stage_want<EXT>(p, se, ep, x.seed_lo, x.seed_hi));
+            const bool miss_b = !stage_hit(tb, stage_want<EXT>(p, se, (ep + 1u) & ~kRecEnded, x.seed_lo, x.seed_hi));
+            need = miss_a || miss_b;
+            want_ep = miss_a ? ep : ((ep + 1u) & ~kRecEnded);
+        }
+        if (threadIdx.x == 0) cnt[0] = 0u;
+        group_sync<W>();
+        if (need) {   // the first epg of them (which ones does not matter; the rest is found again when the window comes round)
+            const uint32_t k = atomicAdd(cnt, 1u);
+            if ((int)k < epg) myhints[k] = make_uint2(se + 1u, want_ep);
+        }
 #ifdef UAVX_STAMPS
         STAMP(1); STAMP(2);
-        stamp_log(stamps, 10u);   // scanned, nothing to draw
+        stamp_log(stamps, __any(need) ? 11u : 10u);   // scanned: left hints / nothing to draw
 #endif
         return;
     }
+    if ((int)threadIdx.x < kHintJobs) myhints[threadIdx.x] = make_uint2(0u, 0u);   // taken
+    if (threadIdx.x == 0) cnt[0] = (uint32_t)n;
+    // the level table (at most 16 x 80 B) rides along into LDS: the chain then reads its env's box from there instead of from
+    // memory (a dependent load behind the level draw)
+    // (16 levels x 5 float4 = 80 rows behind the 64 rows the chain of a one-wavefront workgroup works on; EXT kernels have 192)
+    constexpr int kLvlF4 = (int)(sizeof(LevelParams) / 16);
+    constexpr bool kLvlLds = EXT && W == 1 && LDS::kRows >= kWave + UAVX_MAX_LEVELS * kLvlF4;
+    static_assert(UAVX_MAX_LEVELS * kLvlF4 <= 2 * kWave, "the level table is two rows per lane");
+    // requested here, put into LDS behind the Philox rounds (the loads' latency rides under those)
+    float4 lvl_row0 = make_float4(0.f, 0.f, 0.f, 0.f), lvl_row1 = lvl_row0;
+    if (kLvlLds && p.n_levels > 0) {
+        const int last = p.n_levels * kLvlF4 - 1;
+        lvl_row0 = reinterpret_cast<const float4 *>(p.levels)[min((int)threadIdx.x, last)];
+        lvl_row1 = reinterpret_cast<const float4 *>(p.levels)[min((int)threadIdx.x + kWave, last)];
+    }
+    group_sync<W>();
     // ---- the chain, one lane per slot ----
     StageMap m;
     uint32_t episode = 0;
@@ -1182,6 +1218,12 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
         episode = m.active ? cnt[2 + 2 * g] : 0u;
     }
     const bool go = m.active;
+    // A hint is one launch old: is the layout still wanted, and may its slot be written NOW?  Same rule as the scan applies --
+    // the env's record and the slot's tag as THIS launch finds them (see the invariant above) -- but the two loads are only
+    // waited for in front of the stores: the Philox rounds, the level and the whole chain run meanwhile on the hinted
+    // (env, episode), and a layout that fails the test is simply not stored.
+    const uint32_t rec_y = p.env_rec[m.e].y;
+    const uint4 tag_now = p.stage_tag[(episode & 1u) * (uint32_t)p.E + m.e];
     group_sync<W>();   // (the job list lives in words the chain's scratch reuses)
     STAMP(1);
     __builtin_amdgcn_s_setprio(3);   // a serial chain the launch must not end up waiting for: issue ahead of the SIMD mates
@@ -1219,6 +1261,12 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
             for (int k = 0; k < 4; k++) cw[q][k] = st[q][k];
     }
     STAMP(3);
+    if (kLvlLds && p.n_levels > 0) {
+        const int t = (int)threadIdx.x;
+        if (t < p.n_levels * kLvlF4) lds.pos[kWave + t] = lvl_row0;
+        if (t + kWave < p.n_levels * kLvlF4) lds.pos[2 * kWave + t] = lvl_row1;
+        group_sync<W>();
+    }
     double lox = p.lox, loy = p.loy, hix = p.hix, hiy = p.hiy;
     float sq2r = p.sq_two_r;
     uint32_t lvl = 0;
@@ -1310,7 +1358,10 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
         }
     }
     STAMP(5);
-    if (go) {
+    const uint32_t ep_now = rec_y & ~kRecEnded;
+    const bool wanted = go && ((episode == ep_now && !(rec_y & kRecEnded)) || episode == ((ep_now + 1u) & ~kRecEnded)) &&
+                        !stage_hit(tag_now, stage_want<EXT>(p, m.e, episode, k0, k1));
+    if (wanted) {
         const uint32_t sl = episode & 1u;   // the slot of this episode's layout
         if (learner) {   // a parked learner sits at +inf with target 0 (what reset_envs_wave leaves in its record)
             p.stage_agent[(sl * (uint32_t)p.E + m.e) * (uint32_t)L + (uint32_t)m.i] =
@@ -1332,7 +1383,7 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
     // the tag goes last, behind every store of the layout it vouches for (it is read by a LATER launch, across a kernel
     // boundary; the order only matters for whoever inspects the arrays while this launch runs: nobody does)
     group_sync<W>();
-    if (go && m.i == 0) {
+    if (wanted && m.i == 0) {
         uint4 tag = stage_want<EXT>(p, m.e, episode, k0, k1);
         tag.w = (tag.w & ~0xFFu) | (EXT ? lvl : 0u);   // the level it drew
         p.stage_tag[(episode & 1u) * (uint32_t)p.E + m.e] = tag;
@@ -1359,13 +1410,16 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
     const int N = NT ? NT : p.N;
-#ifndef UAVX_X_NOSTAGE
-    if (blockIdx.x < x.pf_blocks) {   // uniform per workgroup
-        stage_ahead<NT, EXT, W>(p, x, lds);
-        return;
+    {
+        // the staging workgroups of the launch: [stage_first, stage_first + pf_blocks) -- in front of the env-workgroups or
+        // behind them (uavx_step_ex picks; one unsigned compare serves both)
+        const uint32_t sb = blockIdx.x - x.stage_first;
+        if (sb < x.pf_blocks) {   // uniform per workgroup
+            stage_ahead<NT, EXT, W>(p, x, lds, sb);
+            return;
+        }
     }
-#endif
-    const LaneMap m = lane_map<NT, EXT, W>(p, blockIdx.x - x.pf_blocks);
+    const LaneMap m = lane_map<NT, EXT, W>(p, blockIdx.x - x.step_first);
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
@@ -1815,6 +1869,10 @@ struct uavx_handle {
     // layouts drawn ahead (stage_ahead): every auto-resetting uavx_step_ex launch carries ceil(G / prefetch_every) staging
     // workgroups in front of its G env-workgroups
     int prefetch_every = 16;   // 0: off
+    uint2 *hints = nullptr;    // [env-workgroups + 1][kHintJobs] what each staging workgroup's last scan found (in the slab)
+    int wave_slots = 8192;     // wavefronts the device holds at once (compute units x 32)
+    int stage_behind = -1;     // staging workgroups behind (1) / in front of (0) the env-workgroups; -1: by launch shape.  A/B
+                               // knob, read once from UAVX_STAGE_BEHIND when the handle is made; results do not depend on it
     bool ext = false;
     uavx_body_rule rule = {5.0, 128, 0, 0};
     LevelTable levels = {};
@@ -2149,7 +2207,14 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.E = num_envs;
     p.env_offset = env_offset;
     h->ext = B > 0;
-    h->prefetch_every = 16;   // layouts drawn ahead by 1/16 of the env-workgroups' worth of staging workgroups per launch
+    // layouts drawn ahead: staging workgroups for E / 64 layouts per launch (each draws floor(64 W / S) of them), i.e. one per 64
+    // env-workgroups without bodies and one per 16 with 8 learners + 16 bodies.  Measured at 65 536 envs with ~70 episode ends
+    // per launch (tools/exp_pf.py): 4 UAVs 7.61 us at 16, 7.38 at 64, 7.58 at 192; 8 UAVs 13.3 / 12.6 / 12.6; 8 + 16 bodies
+    // 21.2 at 16, 22.6 at 64 -- fewer and an env's second episode end finds nothing parked, more and they crowd the launch
+    {
+        const int lps = std::max(1, kWave * h->gw / (N + B));
+        h->prefetch_every = std::max(1, 64 * lps / std::max(1, p.epw));
+    }
     apply_body_rule(h);
     h->levels.l[0] = make_level(*cfg, nullptr, N, B);
 
@@ -2178,6 +2243,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_sbpos = off;  off = align_up(off + 2 * E * (size_t)B * sizeof(float2), 256);
     const size_t o_sbleg = off;  off = align_up(off + 2 * E * (size_t)B * sizeof(float4), 256);
     const size_t o_stag = off;   off = align_up(off + 2 * E * sizeof(uint4), 256);
+    const size_t o_hint = off;   off = align_up(off + ((E + p.epw - 1) / p.epw + 1) * kHintJobs * sizeof(uint2), 256);   // (staging workgroups <= env-workgroups)
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     h->slab_bytes = off;
@@ -2206,6 +2272,14 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.stage_bpos = reinterpret_cast<float2 *>(b + o_sbpos);
     p.stage_bleg = reinterpret_cast<float4 *>(b + o_sbleg);
     p.stage_tag = reinterpret_cast<uint4 *>(b + o_stag);   // zero-filled: no layout is valid yet
+    h->hints = reinterpret_cast<uint2 *>(b + o_hint);      // zero-filled: no hints
+    if (const char *sb = getenv("UAVX_STAGE_BEHIND")) h->stage_behind = atoi(sb);
+    {
+        int cus = 0, tpc = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+            hipDeviceGetAttribute(&tpc, hipDeviceAttributeMaxThreadsPerMultiProcessor, device) == hipSuccess && cus > 0 && tpc >= kWave)
+            h->wave_slots = cus * (tpc / kWave);
+    }
     p.magic_s = 65536 / (N + B) + 1;
     p.world_version = 1;
     hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);  // level 0 = the config
@@ -2448,10 +2522,24 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     const bool resets = a->reset_policy != UAVX_RESET_NEVER || a->step_cap != 0;
     x.use_stage = (h->prefetch_every > 0 && resets) ? 1 : 0;
     x.pf_blocks = 0; x.pf_groups = grid.x;
+    x.stage_first = 0; x.step_first = 0;
+    x.hints = h->hints;
     dim3 launch = grid;
     if (x.use_stage) {
         x.pf_blocks = (grid.x + (unsigned)h->prefetch_every - 1u) / (unsigned)h->prefetch_every;
         launch.x = grid.x + x.pf_blocks;
+        // Where in the launch?  Workgroups are dispatched in block order.  While the env-workgroups leave wavefront slots free
+        // (65 536 x 4: 4 096 of 8 192) the staging workgroups go IN FRONT and run beside them.  When the env-workgroups alone fill
+        // every slot (65 536 x 8, with or without bodies: exactly 8 192 one-wavefront workgroups), whatever comes on top waits
+        // for a slot: in front, 512 step wavefronts start 4-12 us late -- the ones behind a drawing workgroup last, and the
+        // launch ends with them (per-wavefront timelines, tools/exp_stamps.py: 19.5 us from first start to last end against
+        // 17.1 without staging).  BEHIND the env-workgroups the staging workgroups start when the first step wavefronts retire
+        // (11 us) and work in the shadow of the ones still running (their ends spread over 10-18 us): nothing that steps is
+        // displaced.  Measured in one session, in front / behind: 8 learners + 16 bodies with levels 22.0 / 21.5 us, without
+        // levels 22.3 / 21.8, 8 UAVs 13.8 / 13.5; 4 UAVs 7.03 / 7.02, half-full and multi-round launches within 1 %.  Workgroups
+        // of several wavefronts (24 UAVs: 42 / 53 us) stay in front: their chain runs on __syncthreads and is long.
+        const bool behind = h->stage_behind < 0 ? (h->gw == 1 && (long)grid.x + (long)x.pf_blocks > (long)h->wave_slots) : h->stage_behind != 0;
+        if (behind) x.stage_first = grid.x; else x.step_first = x.pf_blocks;
     }
     dispatch(h, StepExLaunch{h, launch, st, x, a});
     UAVX_HIP(h, hipGetLastError());

@@ -266,7 +266,8 @@ typedef struct {
  * per-env episode statistics (also by uavx_reset). */
 int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
 
-/* Layouts drawn ahead of time (default: every = 16).  The start / target layout of an env's next episode depends only on
+/* Layouts drawn ahead of time (default: every = 64 without scripted bodies, 64 * floor(64 / slots) / envs-per-workgroup
+ * with them -- 16 for 8 learners + 16 bodies: staging workgroups for num_envs / 64 layouts per launch).  The start / target layout of an env's next episode depends only on
  * (seed, global env id, episode index, level rule), so every uavx_step_ex launch with an auto-reset policy or a step cap
  * carries ceil(G / every) extra workgroups in front of its G env-workgroups.  They step nothing: each looks at one window of
  * envs (a lane per env; every window comes round every few launches), finds the envs whose parked layouts -- an env keeps

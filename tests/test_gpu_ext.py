@@ -146,15 +146,18 @@ def test_config5_combined_vs_oracle(amd, oracle_mod, prefetch):
     env.close()
 
 
-@pytest.mark.parametrize("cap,L,B", [(1, 8, 16), (2, 8, 16), (2, 3, 5), (1, 4, 0), (2, 24, 0), (2, 13, 0)])
-def test_staging_overlaps_the_reset_it_serves(amd, oracle_mod, cap, L, B):
+@pytest.mark.parametrize("cap,L,B,behind", [(1, 8, 16, 0), (1, 8, 16, 1), (2, 8, 16, 1), (2, 3, 5, 0), (2, 3, 5, 1), (1, 4, 0, 0), (1, 4, 0, 1),
+                                            (2, 24, 0, 0), (2, 13, 0, 1)])
+def test_staging_overlaps_the_reset_it_serves(amd, oracle_mod, monkeypatch, cap, L, B, behind):
     """Episodes of one and two steps with staging workgroups in EVERY launch (prefetch every = 1): each launch re-initialises
     half (or a third) of the envs from the parked layouts while staging workgroups of the same launch scan, and redraw, the
-    layouts of those very envs.  What keeps that correct is written down at stage_ahead (csrc/uavx_multi.hip): the slot a
-    re-initialising env reads is left alone while its "ended" mark stands, and the mark is cleared by the env's last store,
-    after every load from the staging arrays has returned.  Every output and the whole state against the oracle, every step;
-    a seed change in the middle invalidates everything that is parked."""
+    layouts of those very envs -- from in front of the env-workgroups and from behind them (the library picks by launch shape;
+    UAVX_STAGE_BEHIND, read when the handle is made, forces either).  What keeps that correct is written down at stage_ahead
+    (csrc/uavx_multi.hip): the slot a re-initialising env reads is left alone while its "ended" mark stands, and the mark is
+    cleared by the env's last store, after every load from the staging arrays has returned.  Every output and the whole state
+    against the oracle, every step; a seed change in the middle invalidates everything that is parked."""
     import torch
+    monkeypatch.setenv("UAVX_STAGE_BEHIND", str(behind))
     E = 4096 if L <= 8 else 1024        # (24 and 13 learners with levels: the extension kernels on 3- and 4-wavefront workgroups)
     kw = dict(num_agents=L, num_bodies=B, body_period=4, x_size=26.0, y_size=22.0, d_sense=9.0, collider_radius=0.6)
     levels = [dict(x_size=20.0, y_size=18.0, collider_radius=0.5, d_sense=8.0, n_active=max(1, L // 2), b_active=B // 2),
@@ -363,7 +366,11 @@ def test_randomized_extension_shapes(amd, oracle_mod):
         kw = dict(num_agents=L, num_bodies=B, body_speed=float(rng.uniform(0.0, 9.0)), body_period=period, body_seed=case,
                   x_size=box, y_size=box * float(rng.uniform(0.7, 1.0)), d_sense=float(rng.uniform(4.0, 16.0)),
                   collider_radius=float(rng.uniform(0.2, 0.9)))
-        env = amd.BatchedMultiUAVWorld2D(E, seed=case, env_offset=3 * case, **kw)
+        os.environ["UAVX_STAGE_BEHIND"] = str(case & 1)      # staging workgroups behind / in front of the env-workgroups
+        try:
+            env = amd.BatchedMultiUAVWorld2D(E, seed=case, env_offset=3 * case, **kw)
+        finally:
+            del os.environ["UAVX_STAGE_BEHIND"]
         orc = oracle_mod.OracleMulti(num_envs=E, nthreads=4, **kw)
         nlev = int(rng.integers(0, 4)) if B or case < 12 else int(rng.integers(1, 4))   # B == 0 needs levels to be an extension handle
         if nlev:

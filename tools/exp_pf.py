@@ -30,7 +30,7 @@ def timeit(pf, kw):
     env.close()
     return dt * 1e6, eps / (K + 5 * R + 300)
 
-for pf in (16, 64, 256, 1024, 0):
+for pf in [int(v) for v in os.environ.get('UAVX_PF_LIST', '16,64,256,1024,0').split(',')]:
     for name, kw in (("agent0", dict(auto_reset="agent0_done", step_cap=1500)), ("none", dict())):
         us, rate = timeit(pf, kw)
         print(f"prefetch {pf:5d} {name:8s} {us:7.2f} us   resets/launch {rate:8.1f}", flush=True)

@@ -63,6 +63,21 @@ for rep in range(3):
         lt = np.sort(start[q])
         print(f"    xcd {x}: step waves {q.sum()}, starts p50 {int(lt[len(lt) // 2])} p90 {int(lt[int(len(lt) * .9)])} p99 {int(lt[int(len(lt) * .99)])} max {lt[-1]}, "
               f"life of the first half {int(np.median((end - start)[q & (start <= lt[len(lt) // 2])]))}, of the last tenth {int(np.median((end - start)[q & (start >= lt[int(len(lt) * .9)])]))}, last end {end[q].max()}")
+    # the device-wide 100 MHz clock (slot 6: first / last stamp of the wavefront, low words): the launch's dispatch timeline
+    rt0, rt1 = (a[:, 6] & 0x7FFFFFFF).astype(np.int64), ((a[:, 6] >> 32) & 0x7FFFFFFF).astype(np.int64)   # (bit 63 is the slot's valid mark)
+    z = rt0.min()
+    rs, re = (rt0 - z) / 100.0, (rt1 - z) / 100.0     # us since the first wavefront of the launch started
+    print(f"  device clock: launch spans {re.max():.2f} us from the first start to the last end")
+    for kd in sorted(set(kind.tolist())):
+        q = kind == kd
+        print(f"    {names.get(kd, kd):26s} n={q.sum():5d} start us p1 {np.percentile(rs[q], 1):5.2f} p50 {np.median(rs[q]):5.2f} p90 {np.percentile(rs[q], 90):5.2f} p99 {np.percentile(rs[q], 99):5.2f} max {rs[q].max():5.2f}"
+              f" | life us p50 {np.median((re - rs)[q]):5.2f} p99 {np.percentile((re - rs)[q], 99):5.2f} | end us p50 {np.median(re[q]):5.2f} p90 {np.percentile(re[q], 90):5.2f} p99 {np.percentile(re[q], 99):5.2f} max {re[q].max():5.2f}")
+    h = np.histogram(rs[sw], bins=np.arange(0, re.max() + 1, 1.0))[0]
+    print("    step-wave starts per us:", h.tolist())
+    h = np.histogram(re[sw], bins=np.arange(0, re.max() + 1, 1.0))[0]
+    print("    step-wave ends per us:  ", h.tolist())
+    late = sw & (rs > np.percentile(rs[sw], 95))
+    print(f"    the last 5 % of step waves to start: start {rs[late].min():.2f}..{rs[late].max():.2f} us, life p50 {np.median((re - rs)[late]):.2f}, end p50 {np.median(re[late]):.2f} max {re[late].max():.2f}; blocks {int(blk[late].min())}..{int(blk[late].max())}")
     life = end - start
     slow = np.argsort(np.where(sw, life, 0))[-12:]
     print("  longest-lived step waves (block, life, mid-start, end-mid):", [(int(blk[i]), int(life[i]), int(mid[i] - start[i]), int(end[i] - mid[i])) for i in slow])
