@@ -862,7 +862,10 @@ __device__ __forceinline__ bool too_close(float sq_two_r, float ax, float ay, fl
 // bpos_out / bleg_out / lvl_out: where the body records and the env's level go -- the live arrays (p.body_pos, p.body_leg,
 // p.lvl_cur), or the staging area of a pre-drawn layout (p.stage_bpos, p.stage_bleg, nullptr: the level then only travels
 // in s.flags).
-constexpr int kChainRows = 4;   // rows of accepted points a clash test reads per trip (8-byte halves of the rows: the points only)
+#ifndef UAVX_CHAINROWS
+#define UAVX_CHAINROWS 4
+#endif
+constexpr int kChainRows = UAVX_CHAINROWS;   // rows of accepted points a clash test reads per trip (8-byte halves of the rows: the points only)
 template <int NT, bool EXT, class LDS>
 __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const LaneMap &m, LDS &lds, bool go,
                                                 uint32_t episode, uint32_t k0, uint32_t k1, AgentRegs &s,
@@ -1132,11 +1135,7 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
 #endif
     const int L = NT ? NT : p.N;
     const int S = EXT ? p.nslots : L;                 // lanes per layout
-#ifdef UAVX_X_EPG1
-    const int epg = (S >= 16) ? 1 : min((kWave * W) / S, kHintJobs);
-#else
     const int epg = min((kWave * W) / S, kHintJobs);    // layouts a staging workgroup draws at once
-#endif
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds.obs);        // job list: word 0 = count, job g = {env, episode} in words 1 + 2 g, 2 + 2 g
     // ---- what did this workgroup's last scan find?  Its own hint slots, ONE scalar load (wave-uniform, through the scalar
     // cache: a few hundred cycles at a moment when a vector load queues behind the first loads of every wavefront of the launch)

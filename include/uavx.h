@@ -267,19 +267,21 @@ typedef struct {
 int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
 
 /* Layouts drawn ahead of time (default: every = 64 without scripted bodies, 64 * floor(64 / slots) / envs-per-workgroup
- * with them -- 16 for 8 learners + 16 bodies: staging workgroups for num_envs / 64 layouts per launch).  The start / target layout of an env's next episode depends only on
- * (seed, global env id, episode index, level rule), so every uavx_step_ex launch with an auto-reset policy or a step cap
- * carries ceil(G / every) extra workgroups in front of its G env-workgroups.  They step nothing: each looks at one window of
- * envs (a lane per env; every window comes round every few launches), finds the envs whose parked layouts -- an env keeps
- * TWO, for its next episode and the one after -- are missing, consumed or drawn for another seed / world / level, and draws
- * the first few of them into a staging area, one lane per slot of the neighbour model.  A step workgroup then re-initialises
- * an env with 16-byte copies instead of running the serial accept / reject chain of MUW:127-153 on one wavefront while the
- * rest of the chip waits for it (with 16 scripted bodies that chain is 8-19 us on its own; profiles/r03_ab_notes.md).  A
- * layout that is not there when it is needed -- first use, a new seed / world / curriculum window (all parked layouts are
- * then worked off again at ceil(G / every) * floor(64 / slots) per launch), two episode ends of one env within a few
- * launches -- is drawn in the step workgroup as before: results are identical either way.  every = 0 switches staging off.
- * No second kernel, stream or event is involved: one launch per call, on `stream`; a captured graph behaves like eager calls
- * (nothing on the host counts launches). */
+ * with them -- 16 for 8 learners + 16 bodies).  The start / target layout of an env's next episode depends only on (seed,
+ * global env id, episode index, level rule), so every uavx_step_ex launch with an auto-reset policy or a step cap carries
+ * ceil(G / every) extra workgroups beside its G env-workgroups (in front of them while those leave wavefront slots free,
+ * behind them when they fill the device on their own).  They step nothing.  Each alternates between two short jobs: it looks
+ * at one window of envs (a lane per env; every window comes round every few launches), finds the envs whose parked layouts
+ * -- an env keeps TWO, for its next episode and the one after -- are missing, consumed or drawn for another seed / world /
+ * level, and notes the first few down; in the next launch it draws those into a staging area, one lane per slot of the
+ * neighbour model (after checking against the env's record that they are still wanted).  A step workgroup then
+ * re-initialises an env with 16-byte copies instead of running the serial accept / reject chain of MUW:127-153 on one
+ * wavefront while the rest of the chip waits for it (with 16 scripted bodies that chain is 8-19 us on its own;
+ * profiles/r03_ab_notes.md).  A layout that is not there when it is needed -- first use, a new seed / world / curriculum
+ * window (all parked layouts are then worked off again over the following launches), two episode ends of one env within a
+ * few launches -- is drawn in the step workgroup as before: results are identical either way.  every = 0 switches staging
+ * off.  No second kernel, stream or event is involved: one launch per call, on `stream`; a captured graph behaves like eager
+ * calls (nothing on the host counts launches). */
 int uavx_set_prefetch(uavx_handle *h, int every);
 
 /* Per-env statistics over the episodes ended so far (by auto-reset or uavx_reset):
