@@ -189,6 +189,45 @@ def test_staging_overlaps_the_reset_it_serves(amd, oracle_mod, monkeypatch, cap,
     env.close()
 
 
+@pytest.mark.parametrize("L,B", [(8, 16), (4, 0)])
+def test_results_do_not_depend_on_the_staging_hints(amd, oracle_mod, L, B):
+    """A staging workgroup draws what its last scan wrote into its hint slots {env + 1, episode} -- after checking against the
+    env's record and the slot's tag that the layout is still wanted.  Here the hint area (the tail of the handle's slab, hence of
+    a snapshot) is overwritten with random pairs twice in the middle of a run with two-step episodes and staging workgroups in
+    every launch: plausible env ids with wrong episodes, right ones by chance, ids past the batch, doubled entries.  Every output
+    and the whole state stay equal to the oracle's, which knows nothing of hints."""
+    import torch
+    E, cap = 4096, 2
+    kw = dict(num_agents=L, num_bodies=B, body_period=4, x_size=26.0, y_size=22.0, d_sense=9.0, collider_radius=0.6)
+    env = amd.BatchedMultiUAVWorld2D(E, seed=5, env_offset=7, **kw)
+    orc = oracle_mod.OracleMulti(num_envs=E, nthreads=8, **kw)
+    env.set_prefetch(1)
+    env.reset(); orc.reset_philox(5, env_offset=7)
+    rng = np.random.default_rng(77)
+    groups = E // (64 // L if B == 0 else 8)              # env-workgroups = staging workgroups at every = 1
+    tail = groups * 8 * 8                                 # eight {uint32, uint32} hint slots per staging workgroup
+    for t in range(40):
+        if t in (9, 22):
+            sd = env.state_dict()
+            snap = sd["snapshot"]
+            junk = np.empty((tail // 8, 2), np.uint32)
+            junk[:, 0] = rng.integers(0, 2 * E, size=tail // 8)       # env + 1: half of them past the batch, 0 = empty
+            junk[:, 1] = rng.integers(0, 24, size=tail // 8)          # episode indices around the real ones (t / 3)
+            k = len(junk[1::7])
+            junk[::7][:k] = junk[1::7]                                # doubled entries
+            snap[snap.numel() - tail:] = torch.from_numpy(junk.view(np.uint8).reshape(-1)).to(snap.device)
+            env.load_state_dict(sd)
+        a = rng.uniform(-1, 1, size=(E, L, 2)).astype(np.float32)
+        obs_g, rew_g, done_g, info = env.step_ex(torch.from_numpy(a).to(env.device), polar=True, auto_reset="agent0_done", step_cap=cap)
+        obs_o, rew_o, done_o, rm_o, en_o, tr_o = orc.step_ex(a, action_mode=1, reset_policy=1, step_cap=cap, seed=5, env_offset=7, with_end=True)
+        ctx = f"L{L} B{B} step {t}"
+        np.testing.assert_array_equal(_np(info["reset_mask"]).astype(np.uint8), rm_o, err_msg=ctx)
+        np.testing.assert_array_equal(_np(done_g).astype(np.uint8), done_o, err_msg=ctx)
+        _compare_state(env, orc, ctx)
+        assert obs_err(_np(obs_g), obs_o) <= TOL and float(np.abs(_np(rew_g) - rew_o).max()) <= TOL, ctx
+    env.close()
+
+
 def test_explicit_env_levels_and_parked_learners(amd, oracle_mod):
     """No bodies; levels assigned per env by the caller; parked learners report obs 0 / reward 0 / done 1 and are nobody's
     neighbour; a one-level curriculum equal to the config reproduces the plain kernels bit for bit."""
