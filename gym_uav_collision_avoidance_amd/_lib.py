@@ -92,10 +92,34 @@ class UWStepArgs(ctypes.Structure):  # uavx_uw_step_args
 _lib = None
 
 
+def _code_only(text):
+    """C / C++ source without comments and without whitespace runs: what the compiler sees, near enough.  String and character
+    literals are kept as they are (a `//` inside one is not a comment)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                    # literal: copy to the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            while i < n and text[i] != "\n":               # (a line comment ending in a backslash continues: not used here)
+                i += 1
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash():
-    """Identity of the kernel sources a measurement belongs to: sha256 over csrc/*.hip, csrc/*.hpp and
-    include/uavx.h (first 16 hex digits).  profiles/*_pmc_summary.json carry it; bench.py drops a summary whose
-    hash is not the one of the sources in the tree."""
+    """Identity of the kernel sources a measurement belongs to: sha256 over the CODE of csrc/*.hip, csrc/*.hpp and
+    include/uavx.h -- comments and whitespace left out, so that a reworded comment does not orphan a profile -- first 16 hex
+    digits.  profiles/*_pmc_summary.json carry it; bench.py drops a summary whose hash is not the one of the sources in the
+    tree; the library embeds it (uavx_build_info) and the loader rebuilds on mismatch."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -103,7 +127,7 @@ def source_hash():
     files.append(os.path.join(os.path.dirname(_HERE), "include", "uavx.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 

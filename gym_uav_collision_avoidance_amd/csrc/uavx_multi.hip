@@ -158,8 +158,8 @@ struct StepExtra {
     uint8_t *ended, *truncated;
     int flags_in_done;   // UAVX_FLAGS_IN_DONE: the three per-env flags travel in bits 1..3 of the env's first done byte
     int use_stage;   // consult the pre-drawn layouts
-    // layouts drawn ahead: the first pf_blocks workgroups of the launch do not step anything -- they draw the layouts of the
-    // NEXT episodes of one slice of the envs (see stage_ahead); env-workgroup w is workgroup pf_blocks + w
+    // layouts drawn ahead: pf_blocks workgroups of the launch do not step anything -- they look for, and draw, the layouts of
+    // the NEXT episodes (see stage_ahead); env-workgroup w is workgroup step_first + w
     uint32_t pf_blocks, pf_groups;   // staging workgroups, env-workgroups of the launch
     uint32_t stage_first, step_first;   // block id of the first staging / first env-workgroup: (0, pf_blocks) or (pf_groups, 0)
     uint2 *hints;                    // [pf_blocks][kHintJobs] {env + 1 (0: none), episode}: what a staging workgroup's last scan found
@@ -1866,7 +1866,7 @@ struct uavx_handle {
     // configs[4] extension: scripted bodies and / or an installed curriculum select the EXT kernel variants
     int gw = 1;  // wavefronts per workgroup of the step / reset / observe launches (pick_group_waves)
     // layouts drawn ahead (stage_ahead): every auto-resetting uavx_step_ex launch carries ceil(G / prefetch_every) staging
-    // workgroups in front of its G env-workgroups
+    // workgroups beside its G env-workgroups
     int prefetch_every = 16;   // 0: off
     uint2 *hints = nullptr;    // [env-workgroups + 1][kHintJobs] what each staging workgroup's last scan found (in the slab)
     int wave_slots = 8192;     // wavefronts the device holds at once (compute units x 32)
