@@ -24,10 +24,10 @@ MODES = {"all": dict(polar=True, track_returns=True, auto_reset="agent0_done", s
          "plain": dict(track_returns=False), "polar_track": dict(polar=True, track_returns=True),
          "cap": dict(polar=True, track_returns=True, step_cap=1500)}
 kw = MODES[os.environ.get("UAVX_STAMP_MODE", "all")]
-for k in range(400):
+for k in range(int(os.environ.get("UAVX_STAMP_WARM", "400"))):
     env.step_ex(ring[k % R], **kw)
 L.uavx_debug_stamps(buf, ctypes.byref(n))
-names = {0: "step", 1: "step+reinit", 4: "step, exact scan", 5: "step+reinit, exact scan", 10: "scan, nothing", 11: "scan, appended", 12: "queued ids needed nothing", 13: "drew layouts"}
+names = {0: "step", 1: "step+reinit", 4: "step, exact scan", 5: "step+reinit, exact scan", 10: "scan, nothing", 11: "scan, left hints", 12: "drawing workgroup, no hints", 13: "drew layouts"}
 for rep in range(3):
     for k in range(3):
         env.step_ex(ring[k % R], **kw)
