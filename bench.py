@@ -615,6 +615,10 @@ def main():
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
                          "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else (",false,true>" if ext else ",false,false>")),
                          "note": note},
+            "world_note": ("fused step_ex with auto-reset: a live world (about 60-80 episode ends per launch at 65 536 envs)" if args.fused else
+                           "plain step, no auto-reset (as the reference's step): the measured regions step a world that is thousands of steps old, "
+                           "its UAVs scattered by the random commands -- 3 % (4 UAVs) to 7 % (8 + 16 bodies) cheaper per launch than a freshly "
+                           "reset one (tools/exp_world_age.py); --fused measures the live world a trainer keeps"),
             "gather_ms": gather_s * 1e3,
             "gather_note": "counter read + one gather of [E,4] episode metrics to rank 0 (once per episode, not per step); "
                            "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",
