@@ -238,12 +238,20 @@ class Stepper:
                 self.step(self.ring[i % self.R])
 
 
+def event_passes(K):
+    """How many back-to-back passes of K launches one device-time region brackets: at least 200 launches, so that the ~10 us
+    device-side start of a graph replay -- which rocprofv3's per-kernel average does not contain -- is a small share of the
+    bracket even when K is 20 (the wall-clock regions `value` comes from are exactly K launches, always)."""
+    return max(1, -(-200 // max(1, K)))
+
+
 def timed_regions(stepper, K, repeats, device, dist=None, events=False):
     """`repeats` regions of exactly K step launches, each bracketed by barrier + synchronize on both sides.  events=False:
     wall-clock regions (nothing but the K launches between the two clock reads): what `value` / `ms_per_step` come from.
     events=True: device time of K step launches from HIP events on the launch stream, in regions of their own (the two event
     records would otherwise sit inside the wall-clock region), each preceded by an untimed pass of the same K launches so that
-    the events bracket kernels, not the host's enqueue latency.  Returns the per-region times of this rank (s or ms)."""
+    the events bracket kernels, not the host's enqueue latency, and spanning event_passes(K) passes (>= 200 launches) per bracket.
+    Returns the per-region times of this rank (s, or ms per K launches)."""
     out = []
     for _ in range(repeats):
         torch.cuda.synchronize(device)
@@ -253,16 +261,19 @@ def timed_regions(stepper, K, repeats, device, dist=None, events=False):
         if events:
             # device time of K step launches: an untimed pass of the same K launches goes first and the two events and the
             # timed pass are enqueued BEHIND it, while it runs, so the host's latency of enqueueing on an idle stream is not
-            # inside the bracket.  What a short region still holds beside its K kernels is the DEVICE-side start of a graph
-            # replay (~10 us per replay, measured: 20 x 5.8 us of kernels come out as 128 us) -- rocprofv3's per-kernel average
-            # does not contain it, which is why a 20-step run also reports roofline_steady (1000-step regions)
+            # inside the bracket.  What a bracket still holds beside its kernels is the DEVICE-side start of every graph
+            # replay (~10 us for an isolated one, ~6 us back to back; a lone 20-step replay: 20 x 5.8 us of kernels come out as
+            # 128 us) -- rocprofv3's per-kernel average does not contain it; hence >= 200 launches per bracket, and a 20-step
+            # run also reports roofline_steady (1000-step regions)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = event_passes(K)
             stepper.run(K)
             ev0.record()
-            stepper.run(K)
+            for _ in range(reps):
+                stepper.run(K)
             ev1.record()
             torch.cuda.synchronize(device)
-            out.append(ev0.elapsed_time(ev1))  # HIP events on the stream the kernels were launched on
+            out.append(ev0.elapsed_time(ev1) / reps)  # HIP events on the stream the kernels were launched on; ms per K launches
         else:
             done = torch.cuda.Event()
             t0 = time.perf_counter()
@@ -624,7 +635,7 @@ def main():
                            "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",
             "ms_per_step_incl_amortised_gather": elapsed * 1e3 / K + gather_s * 1e3 / 1500.0,
             "episode_metrics": summ,
-            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + 2 * len(devs)),   # (event regions: an untimed pass + the timed one)
+            "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + (1 + event_passes(K)) * len(devs)),   # (event regions: an untimed pass + the timed ones)
         }
         if args.world == "multi":
             rv = valu_roofline(kernel_name, shape, kernel_s)
