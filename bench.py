@@ -333,6 +333,35 @@ def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60)
                                            "achievable HBM rate on MI355X is ~6.3 TB/s (0.79 of the 8 TB/s spec peak)")
 
 
+def open_loop_point(E, N, device, gen, K=32, reps=40):
+    """uavx_step_k: K consecutive steps of the same step body in ONE launch from an action tape, every step's observations /
+    rewards / dones written out (open-loop rollouts: scripted or pre-drawn commands).  No kernel boundary between steps and the
+    agent state stays in registers, so what is left is the step body itself: the figure to hold against the vector-instruction
+    ceiling.  Informational (a trainer with a policy in the loop cannot use it), never `value`."""
+    from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D
+    env = BatchedMultiUAVWorld2D(E, num_agents=N, device=device, seed=0)
+    env.reset()
+    tape = polar_actions(gen, (K, E, N), float(np.sqrt(200.0)), device)
+    env.step_k(tape, tape_out=True)
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        out = env.step_k(tape, tape_out=True)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    us = ev0.elapsed_time(ev1) * 1e3 / (reps * K)
+    env.close()
+    del out, tape
+    torch.cuda.empty_cache()
+    res = {"K": K, "tape_out": True, "us_per_step": us, "value": E / us * 1e6, "unit": "env-steps/s",
+           "note": "uavx_step_k: K steps per launch from an action tape, all outputs of every step written; informational"}
+    rv = valu_roofline(f"uavx::step_kernel<{N if N in (1, 2, 4, 8) else 0}", f"{E}x{N}", us * 1e-6)
+    if rv is not None:   # same step body: the single-step kernel's instruction count per wavefront stands for it
+        res["valu_frac"] = rv["frac"]
+    return res
+
+
 def split_batch_point(E, N, device, gen, ring_len, bodies=0, chains=2, steps=1000, warmup=100):
     """The same batch as `chains` handles of E / chains envs, each replaying its OWN hipGraph on its OWN stream: independent
     step chains (what a trainer that double-buffers env halves has: the policy works on one half while the other steps).
@@ -667,6 +696,12 @@ def main():
             del ring
             torch.cuda.empty_cache()
             line["roofline_large"] = large_batch_point(N, device, gen, bodies=B)
+            if not B and not args.curriculum:
+                try:   # an extra measurement must never cost the line
+                    line["open_loop_step_k"] = open_loop_point(E, N, device, gen)
+                except Exception as exc:
+                    print(f"[bench] open_loop_step_k skipped ({type(exc).__name__}: {exc})", file=sys.stderr)
+                    torch.cuda.synchronize(device)
             if args.mode == "graph" and not args.curriculum and E % 2 == 0:
                 try:   # an extra measurement must never cost the line
                     line["split_batch"] = split_batch_point(E, N, device, gen, min(args.ring, 50), bodies=B)
