@@ -219,7 +219,8 @@ class BatchedMultiUAVWorld2D(_Base):
         """Reset layouts drawn ahead of time (uavx_set_prefetch): every auto-resetting step_ex launch carries one staging
         workgroup per `every` env-workgroups; each looks at a window of envs and draws the missing layouts of their next
         episodes.  0 / False = off (every auto-reset draws in place, inside its step workgroup).  The handle starts with a
-        cadence sized for num_envs / 64 layouts per launch (64 without scripted bodies, 16 with 8 learners + 16 bodies).
+        cadence sized for num_envs / 128 layouts per launch (32 at 4 UAVs, 64 at 8, 16 with 8 learners + 16 bodies): lower it
+        when episodes are much shorter than 128 steps.
         Results do not depend on it."""
         _lib.check(self._L.uavx_set_prefetch(self._h, int(every)), self._h)
 

@@ -2206,12 +2206,14 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.E = num_envs;
     p.env_offset = env_offset;
     h->ext = B > 0;
-    // layouts drawn ahead: staging workgroups for E / 64 layouts per launch (each draws floor(64 W / S) of them), i.e. one per 64
-    // env-workgroups without bodies and one per 16 with 8 learners + 16 bodies.  Measured at 65 536 envs with ~70 episode ends
-    // per launch (tools/exp_pf.py): 4 UAVs 7.61 us at 16, 7.38 at 64, 7.58 at 192; 8 UAVs 13.3 / 12.6 / 12.6; 8 + 16 bodies
-    // 21.2 at 16, 22.6 at 64 -- fewer and an env's second episode end finds nothing parked, more and they crowd the launch
+    // layouts drawn ahead: a staging workgroup draws up to min(floor(64 W / S), 8) layouts every other launch (it scans in
+    // between), and there are enough of them for E / 128 layouts per launch -- what a batch whose episodes last 128 steps on
+    // average consumes (a random-initialised actor: 170-190 steps at 4 UAVs, tools/closed_loop.py; shorter episodes draw the
+    // excess in place): one per 32 env-workgroups at 4 UAVs, per 64 at 8, per 16 with 8 learners + 16 bodies.  At ~70 episode
+    // ends per launch (bench.py --fused) the launch time is flat from 16 to 256 (4 UAVs) / 8 to 64 (8 + 16); with ~350 per launch
+    // 64 at 4 UAVs already falls behind (env launch of the closed loop 8.0 -> 9.4 us).
     {
-        const int lps = std::max(1, kWave * h->gw / (N + B));
+        const int lps = std::min(kHintJobs, std::max(1, kWave * h->gw / (N + B)));
         h->prefetch_every = std::max(1, 64 * lps / std::max(1, p.epw));
     }
     apply_body_rule(h);

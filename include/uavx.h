@@ -266,8 +266,8 @@ typedef struct {
  * per-env episode statistics (also by uavx_reset). */
 int uavx_step_ex(uavx_handle *h, const uavx_step_args *args, void *stream);
 
-/* Layouts drawn ahead of time (default: every = 64 without scripted bodies, 64 * floor(64 / slots) / envs-per-workgroup
- * with them -- 16 for 8 learners + 16 bodies).  The start / target layout of an env's next episode depends only on (seed,
+/* Layouts drawn ahead of time (default: every = 64 * min(floor(64 / slots), 8) / envs-per-workgroup -- 32 at 4 UAVs, 64 at 8,
+ * 16 for 8 learners + 16 bodies: staging workgroups for num_envs / 128 layouts per launch, what episodes of 128 steps consume).  The start / target layout of an env's next episode depends only on (seed,
  * global env id, episode index, level rule), so every uavx_step_ex launch with an auto-reset policy or a step cap carries
  * ceil(G / every) extra workgroups beside its G env-workgroups (in front of them while those leave wavefront slots free,
  * behind them when they fill the device on their own).  They step nothing.  Each alternates between two short jobs: it looks
