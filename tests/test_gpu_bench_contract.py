@@ -54,6 +54,8 @@ def test_driver_sized_run_is_a_pure_graph_replay():
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 1
     assert d["steps_executed"] == 3 + 5 + (5 + 5 * 11) * 20    # capture warm-up + warm-up + 5 wall-clock regions of exactly 20 launches + 5 device-time regions (an untimed pass + ten timed ones each: >= 200 launches per event bracket; counted before roofline_steady runs)
     assert d["value"] > 7e9, d["value"]   # 20 x ~6.3 us of kernels + one graph launch; 9-10 G on a quiet box
+    ol = d["open_loop_step_k"]            # informational: K steps per launch from an action tape (uavx_step_k), never `value`
+    assert ol["K"] == 32 and ol["tape_out"] and ol["value"] > d["value"] and "valu_frac" in ol
     st = d["roofline_steady"]             # the same launches over 1000-step regions, next to the 20-step figure
     assert st["steps"] == 1000 and st["frac"] >= 0.93 * d["roofline"]["frac"] and st["kernel_us"] > 3.0   # (box noise; both are pure device time now)
     assert d["roofline"]["kernel_us"] < 1e3 * d["ms_per_step"]   # the wall-clock region holds one graph-launch latency, the event region none
