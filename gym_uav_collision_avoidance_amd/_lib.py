@@ -93,15 +93,22 @@ _lib = None
 
 
 def _code_only(text):
-    """C / C++ source without comments and without whitespace runs: what the compiler sees, near enough.  String and character
-    literals are kept as they are (a `//` inside one is not a comment)."""
-    out, i, n = [], 0, len(text)
+    """C / C++ source without comments and with every whitespace run outside a literal reduced to one blank: what the compiler
+    sees, near enough.  String and character literals are kept byte for byte (a `//` inside one is not a comment)."""
+    import re
+    out, code, i, n = [], [], 0, len(text)
+
+    def flush():                                          # the code since the last literal, blanks squeezed
+        if code:
+            out.append(re.sub(r"\s+", " ", "".join(code)))
+            code.clear()
     while i < n:
         c = text[i]
         if c in "\"'":                                    # literal: copy to the closing quote
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1
+            flush()
             out.append(text[i:j + 1]); i = j + 1
         elif text.startswith("//", i):
             while i < n and text[i] != "\n":               # (a line comment ending in a backslash continues: not used here)
@@ -109,10 +116,11 @@ def _code_only(text):
         elif text.startswith("/*", i):
             j = text.find("*/", i + 2)
             i = n if j < 0 else j + 2
-            out.append(" ")
+            code.append(" ")
         else:
-            out.append(c); i += 1
-    return " ".join("".join(out).split())
+            code.append(c); i += 1
+    flush()
+    return "".join(out).strip()
 
 
 def source_hash():

@@ -389,3 +389,34 @@ def test_bench_gpus_n_starts_its_own_ranks():
     text = out.stderr + out.stdout
     assert out.returncode != 0
     assert "no CPU fallback" in text and "launcher must start" not in text, text[-2000:]
+
+
+def test_source_hash_ignores_comments_and_follows_code(tmp_path, monkeypatch):
+    """The identity a profile / a built library carries (`_lib.source_hash`) is taken over the CODE of the kernel sources: a
+    reworded comment or re-indented line must not orphan a profile, a changed token must.  Literals are code (`//` inside a
+    string is not a comment)."""
+    from gym_uav_collision_avoidance_amd import _lib
+    a = 'int f() { return 1; }   // one\n/* block\n   comment */ const char *s = "// not a comment"; char q = \'"\';\n'
+    b = 'int f() {\n    return 1;\n}\nconst char *s = "// not a comment";   /* other words */   char q = \'"\';   // two\n'
+    assert _lib._code_only(a) == _lib._code_only(b)
+    assert _lib._code_only(a) != _lib._code_only(a.replace("return 1", "return 2"))
+    assert _lib._code_only(a) != _lib._code_only(a.replace("// not a comment", "// not  a comment"))   # inside the literal: code
+    # the hash of the tree: stable under a comment appended to a kernel source, moved by a token
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    inc = tmp_path / "include"
+    inc.mkdir()
+    (csrc / "k.hip").write_text("__global__ void k(int *p) { *p = 1; }\n")
+    (csrc / "d.hpp").write_text("// helpers\nstatic int two() { return 2; }\n")
+    (inc / "uavx.h").write_text("/* ABI */\nint uavx_version(void);\n")
+    pkg = tmp_path / "pkg"
+    pkg.mkdir()
+    monkeypatch.setattr(_lib, "CSRC", str(csrc))
+    monkeypatch.setattr(_lib, "_HERE", str(pkg))
+    (tmp_path / "pkg").rmdir()
+    monkeypatch.setattr(_lib, "_HERE", str(tmp_path / "x"))      # include/ is looked up next to the package directory's parent
+    h0 = _lib.source_hash()
+    (csrc / "k.hip").write_text("// a new comment\n__global__ void k(int *p) {\n    *p = 1;   // same code\n}\n")
+    assert _lib.source_hash() == h0
+    (csrc / "k.hip").write_text("__global__ void k(int *p) { *p = 2; }\n")
+    assert _lib.source_hash() != h0
