@@ -422,28 +422,61 @@ def self_launch(n_ranks, argv):
     """`python bench.py --gpus N` (N > 1) without a launcher around it: run
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`
     as a child process and return its exit code.  Signals that end this process are passed on to the child's process
-    group so that a driver-side timeout does not leave ranks behind."""
+    group so that a driver-side timeout does not leave ranks behind: the handlers are installed BEFORE the child exists
+    (a signal that arrives in between is remembered and delivered as soon as it does).  The rendezvous port comes from
+    bind / close, so another process can take it before torchrun binds it: a child that dies on exactly that (address in
+    use) is started once more on a fresh port."""
+    import collections
     import signal
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    import threading
+    state = {"proc": None, "pending": None}
 
     def forward(signum, _frame):
+        proc = state["proc"]
+        if proc is None:
+            state["pending"] = signum
+            return
         try:
             os.killpg(proc.pid, signum)
         except OSError:
             pass
     for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
         signal.signal(sig, forward)
-    return proc.wait()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # see main(): the ranks set the same default themselves
+    rc = 1
+    for attempt in range(2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        if state["pending"] is not None:
+            return 128 + state["pending"]
+        tail = collections.deque(maxlen=400)   # the child's stderr streams through; its tail tells a port clash from any other failure
+
+        def pump(pipe):
+            for line in iter(pipe.readline, ""):
+                tail.append(line)
+                sys.stderr.write(line)
+                sys.stderr.flush()
+        state["proc"] = subprocess.Popen(cmd, env=env, start_new_session=True, stderr=subprocess.PIPE, text=True, bufsize=1)
+        if state["pending"] is not None:
+            forward(state["pending"], None)
+        reader = threading.Thread(target=pump, args=(state["proc"].stderr,), daemon=True)
+        reader.start()
+        rc = state["proc"].wait()
+        reader.join(timeout=10)
+        state["proc"] = None
+        text = "".join(tail)
+        clash = rc != 0 and ("EADDRINUSE" in text or "ddress already in use" in text)
+        if not clash or state["pending"] is not None:
+            break
+        print(f"[bench] rendezvous port {port} was taken before torchrun bound it; starting the ranks once more", file=sys.stderr)
+    return rc
 
 
 def main():
@@ -452,7 +485,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=5, help="timed K-step regions; the median is reported")
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65 536: BASELINE configs[2] on every GPU; "
+                                                          "configs[3] is --gpus 8 --envs 32768)")
     ap.add_argument("--agents", type=int, default=4, help="learning UAVs per env")
     ap.add_argument("--bodies", type=int, default=0,
                     help="scripted dynamic obstacles per env, stepped in-kernel (BASELINE configs[4]: --agents 8 --bodies 16)")
@@ -483,6 +517,14 @@ def main():
     ap.add_argument("--no-large", action="store_true",
                     help="skip the extra measurements: the HBM-sized second roofline point (1 Mi envs) and roofline_steady")
     args = ap.parse_args()
+    # dmabuf IPC.  The host driver of this pool supports no other kind: without this variable RCCL (and any sharing of device
+    # memory between processes) fails with `hipIpcGetMemHandle: invalid argument` (the pool's environment notes; exported there
+    # already).  Set HERE, before the first call that initialises the GPU, so that ranks started by an outer torchrun and ranks
+    # started by self_launch() run in the same environment; a value the caller exported wins.  Reported in the line (`hsa_env`).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    envs_defaulted = args.envs is None
+    if envs_defaulted:
+        args.envs = 65536
     if args.cfg5:
         args.agents, args.bodies, args.fused, args.replay = 8, 16, True, True
         args.curriculum = args.curriculum or 4
@@ -496,6 +538,9 @@ def main():
         # not touched the GPU yet (importing torch does not initialise HIP) and never will: the ranks are CHILD processes
         # (no exec from here), their stdout is ours, so rank 0's JSON line streams through, and we leave with their exit code.
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.gpus > 1 and envs_defaulted and int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] --gpus {args.gpus} with the default 65 536 envs PER GPU (configs[2] on every GPU, {65536 * args.gpus} in all); "
+              f"BASELINE configs[3] (262 144 envs over 8 GPUs) is --gpus 8 --envs 32768", file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -520,7 +565,12 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"--gpus {world}: this process sees {torch.cuda.device_count()} GPU(s); one rank per GPU is the "
+                                 f"contract (UAVX_REHEARSAL=1 shares GPU 0 over gloo, for rehearsals only)")
             dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group of {dist.get_world_size()} ranks, WORLD_SIZE={world}")
 
     from gym_uav_collision_avoidance_amd import BatchedMultiUAVWorld2D, BatchedUAVWorld2D
     from gym_uav_collision_avoidance_amd.replay import DeviceReplay
@@ -596,7 +646,17 @@ def main():
     torch.cuda.synchronize(device)
     gather_s = time.perf_counter() - tg
 
+    ranks_info = None
     if distributed:
+        # every rank's own figures first (one all_gather of a few numbers: off the clock), then the slowest rank per region
+        props = torch.cuda.get_device_properties(device)
+        mine = dict(rank=rank, local_rank=local_rank, device=torch.cuda.current_device(), name=props.name,
+                    pci_bus_id=f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}",
+                    uuid=str(getattr(props, "uuid", "")), pid=os.getpid(),
+                    ms_per_step=statistics.median(walls) * 1e3 / K, kernel_us=statistics.median(devs) * 1e3 / K,
+                    hsa_enable_ipc_mode_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+        ranks_info = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_info, mine)
         t = torch.tensor([walls, devs, [gather_s] * len(walls)], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # per region: the slowest rank
         walls, devs, gather_s = t[0].tolist(), t[1].tolist(), float(t[2][0])
@@ -616,12 +676,20 @@ def main():
         shape = (f"{E}x{N}" + (f"+{B}" if B else "") + ("f" if args.fused else "")   # the tag tools/profile_round.sh files it under
                  + (f"c{args.curriculum}" if args.curriculum else "") + ("r" if args.replay else "") + ("p" if args.packed_flags else ""))
         traffic = measured_traffic(kernel_name, shape) if args.world == "multi" else None
+        pmc_hit = measured_pmc(kernel_name, shape) if args.world == "multi" else None
+        pmc_taken = (pmc_hit[0].get("_meta", {}).get("taken_utc") if pmc_hit else None)
         ws = working_set_bytes(E, slots, N, args.ring) if args.world == "multi" else E * (40 + 2 * 16 + 5 + args.ring * 8)
         if args.replay:   # every slot of the ring has its own obs / reward / done / flag rows
             ws += E * (args.ring - 1) * (N * 45 + 3)
         world_name = "MultiUAVWorld2D" if args.world == "multi" else "UAVWorld2D"
-        if args.world == "multi" and E == 65536 and N == 4 and B == 0:
-            cfg_tag = "BASELINE.json configs[2]"
+        if args.world == "multi" and N == 4 and B == 0 and total_envs == 262144 and world > 1:
+            cfg_tag = f"BASELINE.json configs[3]: 262 144 envs sharded over {world} GPUs by env index"
+        elif args.world == "multi" and E == 65536 and N == 4 and B == 0:
+            cfg_tag = "BASELINE.json configs[2]" + (f" on each of {world} GPUs (weak scaling; configs[3] is --gpus 8 --envs 32768)" if world > 1 else "")
+        elif args.world == "multi" and E == 4096 and N == 1 and B == 0 and world == 1:
+            cfg_tag = "BASELINE.json configs[1]"
+        elif args.world == "uw" and E == 4096 and world == 1:
+            cfg_tag = "BASELINE.json configs[1], UAVWorld2D"
         elif args.world == "multi" and E == 65536 and N == 8 and B == 16:
             cfg_tag = "BASELINE.json configs[4]: 8 learners + 16 scripted dynamic obstacles (extension, parity unpinned by the reference)"
         else:
@@ -636,6 +704,24 @@ def main():
                    "exceeds the 256 MiB Infinity Cache: HBM-streaming"))
         if args.world == "multi":
             note += bytes_note
+        # how old the stepped world was in the regions the figures come from (launches since the reset at the top of this run)
+        n_rep = len(walls)
+        age0 = getattr(stepper, "capture_warmup", 0) + W
+        ev_launches = (1 + event_passes(K)) * K
+        world_age = {"wall_regions": [age0, age0 + n_rep * K], "event_regions": [age0 + n_rep * K, age0 + n_rep * K + len(devs) * ev_launches],
+                     "unit": "step launches since reset"}
+        if args.fused:
+            ended = summ.get("ended_episodes", {}).get("episodes", 0) if isinstance(summ.get("ended_episodes"), dict) else 0
+            total_launches = world_age["event_regions"][1]
+            world_note = (f"fused step_ex with auto-reset: a live world -- {ended} episodes ended over the {total_launches} launches of this run "
+                          f"({ended / max(1, total_launches):.1f} per launch over {E} envs)")
+        else:
+            world_note = (f"plain step, no auto-reset (as the reference's step): the wall-clock regions `value` comes from stepped a world "
+                          f"{world_age['wall_regions'][0]}-{world_age['wall_regions'][1]} launches after its reset, the device-time regions "
+                          f"`roofline` comes from one {world_age['event_regions'][0]}-{world_age['event_regions'][1]} launches old "
+                          f"({n_rep} wall-clock regions of {K} launches, then the event regions); separately measured, not in this run: random commands scatter the UAVs, "
+                          "and a world several thousand launches old steps 3 % (4 UAVs) to 7 % (8 + 16 bodies) cheaper than a freshly reset "
+                          "one (tools/exp_world_age.py, profiles/HISTORY.md); --fused measures the live world a trainer keeps")
         line = {
             "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -647,18 +733,22 @@ def main():
                                    + (", flags packed into the done bytes" if args.packed_flags else "")
                                    + (f", randomized-reset curriculum over {args.curriculum} levels" if args.curriculum else "")
                                    + (f", outputs written zero-copy into a {args.ring}-slot on-device replay ring" if args.replay else ""),
-                       "envs_per_gpu": E, "agents": N, "bodies": B, "curriculum_levels": args.curriculum, "replay": bool(args.replay), "parallelism": f"env-index shard x{world}", "mode": mode,
+                       "envs_per_gpu": E, "agents": N, "bodies": B, "curriculum_levels": args.curriculum, "replay": bool(args.replay),
+                       **({"body_model": "legs-v3 (include/uavx.h uavx_set_body_rule: bodies step before the learners, fixed legs; this "
+                                         "build's own definition since round 3 -- round-2 figures used the costlier waypoint model)"} if B else {}), "parallelism": f"env-index shard x{world}", "mode": mode,
                        "graph_replays": replays},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
+                         "traffic_measured_in_this_run": False,
+                         "traffic_note": ("no PMC pass of this build and shape under profiles/" if not traffic else
+                                          f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, read from {traffic[1]} "
+                                          f"(taken {pmc_taken or 'at an unrecorded time'}, on the kernel sources with the hash of the loaded library); "
+                                          "counters cannot be collected inside a timed run"),
                          "bytes_per_launch": bytes_per_launch, "kernel_us": kernel_s * 1e6,
                          "kernel": kernel_name + ("" if kernel_name.endswith("kernel") else (",false,true>" if ext else ",false,false>")),
                          "note": note},
-            "world_note": ("fused step_ex with auto-reset: a live world (about 60-80 episode ends per launch at 65 536 envs)" if args.fused else
-                           "plain step, no auto-reset (as the reference's step): the measured regions step a world that is thousands of steps old, "
-                           "its UAVs scattered by the random commands -- 3 % (4 UAVs) to 7 % (8 + 16 bodies) cheaper per launch than a freshly "
-                           "reset one (tools/exp_world_age.py); --fused measures the live world a trainer keeps"),
+            "world_note": world_note, "world_age": world_age,
             "gather_ms": gather_s * 1e3,
             "gather_note": "counter read + one gather of [E,4] episode metrics to rank 0 (once per episode, not per step); "
                            "amortised over a 1500-step episode it adds gather_ms/1500 to ms_per_step",
@@ -666,6 +756,23 @@ def main():
             "episode_metrics": summ,
             "steps_executed": getattr(stepper, "capture_warmup", 0) + W + K * (len(walls) + (1 + event_passes(K)) * len(devs)),   # (event regions: an untimed pass + the timed ones)
         }
+        line["hsa_env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        if distributed:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+            line["distributed"] = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                                   "rccl_version": None if rehearsal else rccl, "rehearsal_shared_gpu": rehearsal,
+                                   "devices_visible": torch.cuda.device_count(),
+                                   "distinct_devices": len({(r["pci_bus_id"], r["device"]) for r in ranks_info}),
+                                   "per_rank": ranks_info,
+                                   "per_rank_ms_per_step": [r["ms_per_step"] for r in ranks_info],
+                                   "note": "value / ms_per_step: per timed region the slowest rank (all_reduce MAX), median region; "
+                                           "per_rank_ms_per_step: each rank's own median region"}
+        if world > 1:
+            line["omitted_for_n_gpus>1"] = ["cpu_baseline", "speedup_vs_cpu_baseline", "roofline_steady", "roofline_large", "latency_us",
+                                            "open_loop_step_k", "split_batch"]
         if args.world == "multi":
             rv = valu_roofline(kernel_name, shape, kernel_s)
             if rv is not None:

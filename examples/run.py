@@ -4,7 +4,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gym_uav_collision_avoidance_amd.envs import UAVWorld2D  # was: gym_uav_collision_avoidance.envs
+import gym_uav_collision_avoidance_amd
+gym_uav_collision_avoidance_amd.install_alias()            # opt-in alias: the reference's import line below then means this build
+from gym_uav_collision_avoidance.envs import UAVWorld2D    # run.py:2, unchanged
 
 env = UAVWorld2D()
 observation, info = env.reset(return_info=True)

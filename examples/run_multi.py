@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""The reference's run_multi.py (random-action demo, run_multi.py:5-23) against the MI355X build:
-only the import changes.  The reference blocks on input() and renders with pygame each step; here the
-loop runs a fixed number of steps and can dump rgb_array frames instead."""
+"""The reference's run_multi.py (random-action demo, run_multi.py:5-23) against the MI355X build, with the reference's
+own import line: install_alias() (opt-in) makes `gym_uav_collision_avoidance` resolve to this build.  The reference blocks
+on input() and renders with pygame each step; here the loop runs a fixed number of steps and can dump rgb_array frames."""
 import argparse
 import os
 import sys
@@ -9,7 +9,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gym_uav_collision_avoidance_amd.envs import MultiUAVWorld2D  # was: gym_uav_collision_avoidance.envs
+import gym_uav_collision_avoidance_amd
+gym_uav_collision_avoidance_amd.install_alias()                 # or: UAVX_ALIAS=1 / PYTHONPATH=<package>/compat
+from gym_uav_collision_avoidance.envs import MultiUAVWorld2D    # run_multi.py:2, unchanged
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)

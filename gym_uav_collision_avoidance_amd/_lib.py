@@ -94,13 +94,15 @@ _lib = None
 
 def _code_only(text):
     """C / C++ source without comments and with every whitespace run outside a literal reduced to one blank: what the compiler
-    sees, near enough.  String and character literals are kept byte for byte (a `//` inside one is not a comment)."""
+    sees, near enough.  String and character literals are kept byte for byte (a `//` inside one is not a comment), and a
+    preprocessor directive keeps its line to itself (where a `#define` ends is code)."""
     import re
+    NL, SP, TB = "\x00", "\x01", "\x02"
     out, code, i, n = [], [], 0, len(text)
 
-    def flush():                                          # the code since the last literal, blanks squeezed
+    def flush():                                          # the code since the last literal (line ends still marked)
         if code:
-            out.append(re.sub(r"\s+", " ", "".join(code)))
+            out.append("".join(code))
             code.clear()
     while i < n:
         c = text[i]
@@ -109,7 +111,7 @@ def _code_only(text):
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1
             flush()
-            out.append(text[i:j + 1]); i = j + 1
+            out.append(text[i:j + 1].replace(" ", SP).replace("\t", TB)); i = j + 1      # blanks of a literal are code
         elif text.startswith("//", i):
             while i < n and text[i] != "\n":               # (a line comment ending in a backslash continues: not used here)
                 i += 1
@@ -118,16 +120,37 @@ def _code_only(text):
             i = n if j < 0 else j + 2
             code.append(" ")
         else:
-            code.append(c); i += 1
+            code.append(NL if c == "\n" else c); i += 1
     flush()
-    return "".join(out).strip()
+    lines, directive = [], False
+    for line in "".join(out).split(NL):
+        body = re.sub(r"[ \t\r\f\v]+", " ", line).strip()
+        if not body:
+            continue
+        starts = body.startswith("#")
+        if starts or directive:                           # a directive (or the continuation of one): its own line
+            lines.append(("\n" if starts else "") + body + ("" if body.endswith("\\") else "\n"))
+            directive = body.endswith("\\")
+        else:
+            lines.append(body + " ")
+    return re.sub(r" +", " ", "".join(lines)).strip().replace(SP, " ").replace(TB, "\t")
+
+
+def build_flags():
+    """What else decides the machine code: the Makefile (comments dropped) and the variables a caller may override it with."""
+    mk = open(os.path.join(CSRC, "Makefile"), "r", encoding="utf-8", errors="replace").read()
+    mk = "\n".join(l.split("#", 1)[0].rstrip() for l in mk.splitlines() if l.split("#", 1)[0].strip())
+    env = ";".join(f"{k}={os.environ[k]}" for k in ("HIPCC", "ARCH", "HIPFLAGS") if k in os.environ)
+    return mk + "\n" + env
 
 
 def source_hash():
-    """Identity of the kernel sources a measurement belongs to: sha256 over the CODE of csrc/*.hip, csrc/*.hpp and
-    include/uavx.h -- comments and whitespace left out, so that a reworded comment does not orphan a profile -- first 16 hex
-    digits.  profiles/*_pmc_summary.json carry it; bench.py drops a summary whose hash is not the one of the sources in the
-    tree; the library embeds it (uavx_build_info) and the loader rebuilds on mismatch."""
+    """Identity of the kernels a measurement belongs to: sha256 over the CODE of csrc/*.hip, csrc/*.hpp and include/uavx.h --
+    comments and whitespace left out, so that a reworded comment does not orphan a profile -- plus the build recipe (the
+    Makefile without its comments and any HIPCC / ARCH / HIPFLAGS override in the environment: -ffp-contract and the -D
+    tuning knobs decide bit-exactness and speed as much as the sources do); first 16 hex digits.  profiles/*_pmc_summary.json
+    carry it; bench.py drops a summary whose hash is not the one of the tree; the library embeds it (uavx_build_info) and
+    the loader rebuilds on mismatch."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -136,6 +159,9 @@ def source_hash():
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
+    if os.path.exists(os.path.join(CSRC, "Makefile")):
+        h.update(b"Makefile")
+        h.update(build_flags().encode())
     return h.hexdigest()[:16]
 
 
@@ -202,10 +228,10 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
     L.uavx_version.restype = i32
-    L.uavx_build_info.restype = ctypes.c_char_p
     if L.uavx_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} speaks ABI version {L.uavx_version()}, this package binds version {ABI_VERSION}: "
                            f"rebuild it (`make -B -C {CSRC}`)")
+    L.uavx_build_info.restype = ctypes.c_char_p      # (exists from ABI version 3 on: bound behind the version check)
     L.uavx_selftest.argtypes = [i32, ctypes.POINTER(ctypes.c_uint64)]
     L.uavx_strerror.restype = ctypes.c_char_p
     L.uavx_strerror.argtypes = [i32]

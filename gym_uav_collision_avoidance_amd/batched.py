@@ -556,6 +556,10 @@ class BatchedMultiUAVWorld2D(_Base):
         if (host["num_envs"], host["num_agents"], host["num_bodies"]) != (self.num_envs, self.num_agents, self.num_bodies):
             raise ValueError("uavx: the state dict was taken from a batch of another shape")
         snap = sd["snapshot"].to(self.device)
+        need = int(self._L.uavx_snapshot_bytes(self._h))
+        if snap.dtype != torch.uint8 or snap.dim() != 1 or not snap.is_contiguous() or snap.numel() < need:
+            raise ValueError(f"uavx: the snapshot must be a contiguous uint8 tensor of at least {need} bytes for this batch "
+                             f"(got {tuple(snap.shape)} {snap.dtype})")
         if snap.data_ptr() % 256:
             blob = torch.empty((snap.numel() + 256,), dtype=torch.uint8, device=self.device)
             off = (-blob.data_ptr()) % 256

@@ -54,6 +54,28 @@ __device__ __forceinline__ void store8_wt(rsrc_t r, uint32_t byte_off, float2 v)
     __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)byte_off, 0, kAuxSc1);
 }
 
+// A kernel argument fetched WHERE IT IS USED.  The compiler treats the kernel-argument segment as invariant, dereferenceable
+// memory and hoists every scalar load from it to the top of the kernel, where the value then occupies scalar registers for the
+// whole life of the wavefront -- also the pointers that only a rare branch (an atomic on a goal arrival, a body's new waypoint)
+// or the last few instructions need.  At 8 wavefronts per SIMD a wavefront has 80 scalar registers (800 per SIMD, 16 of each
+// wavefront's share set aside for the trap handler, blocks of 16): the step kernels with scripted bodies went over and spilled
+// such pointers into VGPR lanes (v_writelane / v_readlane).  Here the segment's address goes through an empty asm, which hides
+// what it points at, so the load stays where it is written: one s_load through the scalar cache at the use (every wavefront of
+// the launch reads the same line) instead of registers held from the first instruction on.
+// `byte_off` is the argument's offset in the segment: offsetof() into the FIRST by-value argument of the kernel.  (Taking the
+// address of a member of the argument itself will not do: an escaping address pins the kernel's private copy of the whole
+// struct into scratch memory.)
+typedef const __attribute__((address_space(4))) char *karg_ptr;
+__device__ __forceinline__ karg_ptr late_kargs() {   // the segment, laundered: loads through it stay behind this point
+    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return ka;
+}
+template <class T>
+__device__ __forceinline__ T late_karg(uint32_t byte_off, karg_ptr ka = late_kargs()) {
+    return *(const __attribute__((address_space(4))) T *)(ka + byte_off);
+}
+
 // Correctly rounded sqrtf in 9 instructions instead of the compiler's 17: v_sqrt_f32 (<= 1 ulp) followed by the
 // same +-1 ulp residual test the compiler's IEEE expansion uses (e = s - c*r for the two neighbours c of r), but
 // WITHOUT its input scaling by 2^32 / output scaling by 2^-16, which only serves s < 2^-96 (v_sqrt_f32 flushes

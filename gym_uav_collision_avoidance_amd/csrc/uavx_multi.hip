@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,47 @@
 #include "uavx_device.hpp"
 
 namespace uavx {
+
+// LATE(on, p, member): p.member -- with `on` (a compile-time flag of the kernel variant) fetched where it is used instead of
+// at the top of the kernel (late_karg(), uavx_device.hpp): for members that only a rare branch or the last instructions of a
+// wavefront need, in the variants whose scalar registers are tight (8 wavefronts per SIMD = 80 SGPRs).  `p` must be the kernel's
+// FIRST argument (it is, in every kernel of this file).  NOT a free lunch, hence per variant: the headline kernel (4 UAVs, 66
+// SGPRs, nothing to gain) lost 0.34 us of 5.85 with its `prev_ovr` / counter pointers fetched late -- the scalar loads at the top
+// regroup (one dwordx8 became a dwordx2 + a dwordx4) and that launch is latency-shaped (profiles/r04_ab_notes.md).
+// -DUAVX_LATE=0 turns every site off (A/B).
+#ifndef UAVX_LATE
+#define UAVX_LATE 1
+#endif
+template <bool ON>
+__device__ __forceinline__ karg_ptr kargs_if() {
+    if constexpr (ON && UAVX_LATE) return late_kargs();
+    else return nullptr;
+}
+template <bool ON, class T>
+__device__ __forceinline__ T karg_if(T plain, uint32_t byte_off) {   // (by value: an unused read of a kernel argument folds away)
+    if constexpr (ON && UAVX_LATE) return late_karg<T>(byte_off);
+    else return plain;
+}
+template <bool ON, class T>
+__device__ __forceinline__ T karg_if(T plain, uint32_t byte_off, karg_ptr ka) {
+    if constexpr (ON && UAVX_LATE) return late_karg<T>(byte_off, ka);
+    else return plain;
+}
+#define LATE(on, p, member) karg_if<(on)>((p).member, (uint32_t)offsetof(MultiParams, member))
+// several members at one place: `LATE_BASE(on, ka);` once, then LATE_AT(on, ka, p, member) (one laundering point for all of them)
+#define LATE_BASE(on, ka) const karg_ptr ka = kargs_if<(on)>()
+#define LATE_AT(on, ka, p, member) karg_if<(on)>((p).member, (uint32_t)offsetof(MultiParams, member), ka)
+// members of uavx_step_ex's options block: the SECOND argument of step_ex_kernel, directly behind the first (static_assert below)
+#define LATE_X(on, x, member) karg_if<(on)>((x).member, (uint32_t)(sizeof(MultiParams) + offsetof(StepExtra, member)))
+#define LATE_X_AT(on, ka, x, member) karg_if<(on)>((x).member, (uint32_t)(sizeof(MultiParams) + offsetof(StepExtra, member)), ka)
+// which sites a variant switches on (bit mask, -DUAVX_LATE_STEP=... for A/B): 1 the counter atomics at the end of a step,
+// 2 a body's new waypoint (stage_bodies), 4 the episode fold, 8 step_ex's re-initialisation block, its tail pointers and flag arrays
+#ifndef UAVX_LATE_STEP
+#define UAVX_LATE_STEP 0      // step_kernel with bodies / levels (one-wavefront workgroups)
+#endif
+#ifndef UAVX_LATE_EX
+#define UAVX_LATE_EX 15       // step_ex_kernel with bodies / levels, and its 8-UAV specialisation
+#endif
 
 struct Goal { float tx, ty, init_d; uint32_t flags; };  // 16 B, one dwordx4 load; flags word stored only on change
 
@@ -164,6 +206,16 @@ struct StepExtra {
     uint32_t stage_first, step_first;   // block id of the first staging / first env-workgroup: (0, pf_blocks) or (pf_groups, 0)
     uint2 *hints;                    // [pf_blocks][kHintJobs] {env + 1 (0: none), episode}: what a staging workgroup's last scan found
 };
+
+static_assert(sizeof(MultiParams) % alignof(StepExtra) == 0, "LATE_X: StepExtra must follow MultiParams without padding in the kernel-argument segment");
+
+// The caller's buffers follow StepExtra in step_ex_kernel's argument list as plain parameters (`__restrict__`: they do not
+// alias, and the compiler orders loads against stores on that knowledge -- handing them over in a struct cost the 4-UAV fused
+// launch 0.2 us of 7.0).  Their places in the kernel-argument segment, for the variants that fetch the two output pointers
+// again at their end (LATE_IO): each parameter sits at the next multiple of its alignment.
+constexpr uint32_t kIoBase = (uint32_t)(sizeof(MultiParams) + sizeof(StepExtra));   // const void *actions
+constexpr uint32_t kIoRew = kIoBase + 24, kIoDone = kIoBase + 32;                    // (int evaluate +8, float *obs_out +16,) rew_out, done_out
+static_assert(sizeof(StepExtra) % 8 == 0, "the pointer parameters behind StepExtra start on its end");
 
 struct LaneMap {
     int lane;        // thread in its workgroup (the lane when the workgroup is one wavefront)
@@ -300,13 +352,19 @@ __device__ __forceinline__ void load_agent(const MultiParams &p, uint32_t a, Age
     if (s.flags & kFlagPrevOvr) s.prev_d = p.prev_ovr[a];  // rare: only after a caller poked the state
 }
 // flags_in: the flags word as loaded (the word is stored only if the step changed it)
-__device__ __forceinline__ void store_agent(const MultiParams &p, uint32_t a, const AgentRegs &s, uint32_t flags_in) {
+// (pos / vel / goal: p's arrays, handed over separately because the register-tight kernels fetch those pointers again at
+//  their end instead of holding them in scalar registers from the loads at the top on, see LATE())
+__device__ __forceinline__ void store_agent(const MultiParams &p, float2 *pos, double2 *vel, Goal *goal, uint32_t a,
+                                            const AgentRegs &s, uint32_t flags_in) {
     // velocity: 16 B per lane, written through (sc1) like the obs tile so that it drains during the launch instead
     // of at the kernel boundary (A/B at 65536x4: 6.71 -> 6.21 us); the 8-byte position store stays plain
     // (narrow sc1 stores are slow: 6.29 us with both)
-    store16_wt(make_rsrc(p.vel, (uint32_t)p.E * (uint32_t)p.N * 16u), a * 16u, make_double2(s.vx, s.vy));
-    p.pos[a] = make_float2(s.x, s.y);
-    if (s.flags != flags_in) p.goal[a].flags = s.flags;
+    store16_wt(make_rsrc(vel, (uint32_t)p.E * (uint32_t)p.N * 16u), a * 16u, make_double2(s.vx, s.vy));
+    pos[a] = make_float2(s.x, s.y);
+    if (s.flags != flags_in) goal[a].flags = s.flags;
+}
+__device__ __forceinline__ void store_agent(const MultiParams &p, uint32_t a, const AgentRegs &s, uint32_t flags_in) {
+    store_agent(p, p.pos, p.vel, p.goal, a, s, flags_in);
 }
 
 // Neighbour scan of one agent over the other N-1 agents of its env (positions staged in LDS).
@@ -431,13 +489,22 @@ __device__ __forceinline__ Neigh scan_neighbours(float sq_sense, const LaneMap &
     auto other = [&](int c, bool below) {   // the c-th other slot of the env as seen from agent i
         return *reinterpret_cast<const float4 *>(rowb + c * 16 + (below ? 0 : 16));
     };
-    if (NT) {  // compile-time N: all LDS reads issued before the first use
+    if (NT) {  // compile-time N: the LDS reads of a batch are issued before its first use
+#ifndef UAVX_SCANBATCH
+#define UAVX_SCANBATCH 7
+#endif
         constexpr int M = NT > 1 ? NT - 1 : 1;
-        float4 q[M];
+        constexpr int BATCH = M < UAVX_SCANBATCH ? M : UAVX_SCANBATCH;
 #pragma unroll
-        for (int c = 0; c < NT - 1; c++) q[c] = other(c, c < m.i);
+        for (int c0 = 0; c0 < NT - 1; c0 += BATCH) {
+            float4 q[BATCH];
 #pragma unroll
-        for (int c = 0; c < NT - 1; c++) visit((uint32_t)c, c < m.i, q[c]);
+            for (int c = 0; c < BATCH; c++)
+                if (c0 + c < NT - 1) q[c] = other(c0 + c, c0 + c < m.i);
+#pragma unroll
+            for (int c = 0; c < BATCH; c++)
+                if (c0 + c < NT - 1) visit((uint32_t)(c0 + c), c0 + c < m.i, q[c]);
+        }
     } else {
         // two neighbours per trip, written out (inline asm is convergent in HIP, which rules out the unroll pragma)
         const int NL = m.nlearn;   // slots [0, NL) are agents with a lane each; [NL, N) scripted bodies (extension)
@@ -632,7 +699,7 @@ __device__ __forceinline__ float4 make_leg(float body_step, float x, float y, fl
 // neighbour row {x, y, x, y} + heading, position stored back (8 B) if it moved.  A body that does not take part (b >= the
 // level's b_active) is staged at +inf.
 //   ready   the env was re-initialised by this call: its bodies' rows were staged by the reset path, they do not move.
-template <bool MOVE, class LDS>
+template <bool MOVE, class LDS, bool LATEW = false>
 __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap &m, LDS &lds, uint32_t flags, bool ready,
                                              uint32_t steps, uint32_t ep_draw) {
     const int L = p.N;
@@ -652,10 +719,12 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
         float4 leg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (on) { q = p.body_pos[gi]; leg = p.body_leg[gi]; }
         if (on && retarget) {
-            const ResetCandidates c = reset_candidates((uint64_t)p.env_offset + m.e, (uint32_t)(L + b),
-                                                       0x80000000u | (steps >> p.body_pshift), ep_draw, p.body_k0,
-                                                       p.body_k1, leveled ? lv->lox : p.lox, leveled ? lv->loy : p.loy,
-                                                       leveled ? lv->hix : p.hix, leveled ? lv->hiy : p.hiy);
+            // (once per `period` steps: LATEW fetches what this needs from the kernel arguments here, not at the top)
+            const ResetCandidates c = reset_candidates((uint64_t)LATE(LATEW, p, env_offset) + m.e, (uint32_t)(L + b),
+                                                       0x80000000u | (steps >> p.body_pshift), ep_draw, LATE(LATEW, p, body_k0),
+                                                       LATE(LATEW, p, body_k1), leveled ? lv->lox : LATE(LATEW, p, lox),
+                                                       leveled ? lv->loy : LATE(LATEW, p, loy), leveled ? lv->hix : LATE(LATEW, p, hix),
+                                                       leveled ? lv->hiy : LATE(LATEW, p, hiy));
             leg = make_leg(p.body_step, q.x, q.y, c.sx, c.sy);
             p.body_leg[gi] = leg;
         }
@@ -674,7 +743,7 @@ __device__ __forceinline__ void stage_bodies(const MultiParams &p, const LaneMap
 //   frozen: the env was re-initialised by this call (auto-reset); the agent only observes.
 //   EXT: env_steps / ep_draw = the env's step count before this step and the episode index its reset drew with
 //        (scripted bodies); frozen envs had their bodies' rows staged by the reset path.
-template <int NT, bool EXT, class LDS>
+template <int NT, bool EXT, class LDS, bool LATEW = false>
 __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &m, LDS &lds, AgentRegs &s, double ax,
                                            double ay, int evaluate, float o[10], float &rew, uint32_t &done_out,
                                            uint32_t &reach_ev, uint32_t &coll_ev, bool frozen = false,
@@ -701,7 +770,7 @@ __device__ __forceinline__ void step_agent(const MultiParams &p, const LaneMap &
         lds.pos[m.rbase + m.i] = make_float4(ox, oy, s.x, s.y);   // a parked learner sits at +inf
         lds.theta[m.rbase + m.i] = theta;
     }
-    if (EXT && p.B > 0) stage_bodies<true>(p, m, lds, s.flags, frozen, env_steps, ep_draw);
+    if (EXT && p.B > 0) stage_bodies<true, LDS, LATEW>(p, m, lds, s.flags, frozen, env_steps, ep_draw);
     group_sync<LDS::kW>();
     const Neigh nb = scan_neighbours<NT, true>(sq_sense, m, lds, s.x, s.y);
     const WorldLims w = world_lims<EXT>(p, s.flags);
@@ -798,15 +867,16 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void s
     const uint32_t flags_in = s.flags;
     float o[10], rew;
     uint32_t dn, re, ce;
-    step_agent<NT, EXT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, false, wave_count - rec.x,
-                        ((rec.y & ~kRecEnded) - 1u) & ~kRecEnded);
+    constexpr int kLate = (EXT && W == 1) ? UAVX_LATE_STEP : 0;   // LATE() sites of this variant
+    step_agent<NT, EXT, LDS, (kLate & 2) != 0>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, false, wave_count - rec.x,
+                                               ((rec.y & ~kRecEnded) - 1u) & ~kRecEnded);
     if (m.active) {
         if (!(EXT && (flags_in & kFlagInactive))) store_agent(p, m.a, s, flags_in);
         rew_out[m.a] = rew;
         done_out[m.a] = (uint8_t)dn;
-        if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
-        if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
-        if (!(fabsf(rew) < INFINITY)) atomicAdd(&p.nonfin[m.e], 1u);   // the tripwire of test_ddpg_multi.py:114-130, per env
+        if (re) atomicAdd(&LATE(kLate & 1, p, reach)[m.e], 1u);                // MUW:221
+        if (ce) atomicAdd(&LATE(kLate & 1, p, coll)[m.e], 1u);                 // MUW:209
+        if (!(fabsf(rew) < INFINITY)) atomicAdd(&LATE(kLate & 1, p, nonfin)[m.e], 1u);   // the tripwire of test_ddpg_multi.py:114-130, per env
         if (m.lane == 0) {
             if (EXT) p.wave_steps[m.wave] = wave_count + 1u;   // single writer: this wave (MUW:238)
             else atomicAdd(&p.wave_steps[m.wave], 1u);         // MUW:238 for every env of this wave (no-return)
@@ -1017,8 +1087,8 @@ __device__ __forceinline__ void reset_envs_wave(const MultiParams &p, const Lane
 
 // What a parked layout must have been drawn for to serve env e's next reset: {episode index, seed, level rule | world
 // version | valid}.  With an installed curriculum and the random window off the level is the one assigned to the env.
-template <bool EXT>
-__device__ __forceinline__ uint4 stage_want(const MultiParams &p, uint32_t e, uint32_t episode, uint32_t k0, uint32_t k1) {
+template <bool EXT, class P>   // P: MultiParams, or the same struct seen through the laundered kernel-argument pointer
+__device__ __forceinline__ uint4 stage_want(const P &p, uint32_t e, uint32_t episode, uint32_t k0, uint32_t k1) {
     uint32_t lvl = 0xFFu;   // "drawn by the layout itself" (random window) or no curriculum
     if (EXT && p.n_levels > 0 && p.level_lo < 0) lvl = min((uint32_t)p.lvl_next[e], (uint32_t)(p.n_levels - 1));
     return make_uint4(episode, k0, k1, kStageValid | ((p.world_version & 0x7FFFFFu) << 8) | lvl);
@@ -1033,23 +1103,27 @@ __device__ __forceinline__ bool stage_hit(uint4 have, uint4 want) {   // the lev
 struct EpisodeFold {
     uint4 c; float2 f; uint32_t reach, coll;
 };
+template <bool LATEF = false>
 __device__ __forceinline__ EpisodeFold fold_load(const MultiParams &p, uint32_t e) {  // all loads up front: one latency
     EpisodeFold v;
-    v.c = p.fin_counts[e]; v.f = p.fin_returns[e];
-    v.reach = p.reach[e]; v.coll = p.coll[e];
+    LATE_BASE(LATEF, ka);
+    v.c = LATE_AT(LATEF, ka, p, fin_counts)[e]; v.f = LATE_AT(LATEF, ka, p, fin_returns)[e];
+    v.reach = LATE_AT(LATEF, ka, p, reach)[e]; v.coll = LATE_AT(LATEF, ka, p, coll)[e];
     return v;
 }
 // An episode of env e ends (reset): fold its counters into the per-env statistics the evaluation loop reads
 // (test_sac_multi.py:157,164-165) and clear them (MUW:167-168).  One lane per env; the caller rewrites env_rec.
+template <bool LATEF = false>
 __device__ __forceinline__ void fold_store(const MultiParams &p, uint32_t e, uint32_t steps, float2 run, EpisodeFold v) {
+    LATE_BASE(LATEF, ka);
     if (steps != 0) {
         v.c.x += 1; v.c.y += steps; v.c.z += v.reach; v.c.w += v.coll;
         v.f.x += run.x; v.f.y += run.y;
-        p.fin_counts[e] = v.c;
-        p.fin_returns[e] = v.f;
+        LATE_AT(LATEF, ka, p, fin_counts)[e] = v.c;
+        LATE_AT(LATEF, ka, p, fin_returns)[e] = v.f;
     }
-    p.reach[e] = 0; p.coll[e] = 0;  // MUW:167-168
-    p.nonfin[e] = 0;
+    LATE_AT(LATEF, ka, p, reach)[e] = 0; LATE_AT(LATEF, ka, p, coll)[e] = 0;  // MUW:167-168
+    LATE_AT(LATEF, ka, p, nonfin)[e] = 0;
 }
 
 // test_sac_multi.py:77-80 in float32: a in [-1,1]^2 -> velocity command.
@@ -1127,8 +1201,8 @@ struct StageMap {   // lane-per-slot mapping of a staging workgroup (the fields 
     bool active;
     uint32_t e;
 };
-template <int NT, bool EXT, int W, class LDS>
-__device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtra &x, LDS &lds, uint32_t sb) {   // sb: which staging workgroup
+template <int NT, bool EXT, int W, class LDS, class P, class X>   // P / X: MultiParams / StepExtra, plain or in the kernel-argument address space
+__device__ __forceinline__ void stage_ahead(const P &p, const X &x, LDS &lds, uint32_t sb) {   // sb: which staging workgroup
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
@@ -1186,7 +1260,6 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
 #endif
         return;
     }
-    if ((int)threadIdx.x < kHintJobs) myhints[threadIdx.x] = make_uint2(0u, 0u);   // taken
     if (threadIdx.x == 0) cnt[0] = (uint32_t)n;
     // the level table (at most 16 x 80 B) rides along into LDS: the chain then reads its env's box from there instead of from
     // memory (a dependent load behind the level draw)
@@ -1202,6 +1275,11 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
         lvl_row1 = reinterpret_cast<const float4 *>(p.levels)[min((int)threadIdx.x + kWave, last)];
     }
     group_sync<W>();
+    // The hints are marked "taken" only BEHIND this barrier: `n` must be the same in every wavefront of the workgroup (W > 1:
+    // each wavefront reads the slots with its own scalar load above), and a clear in front of the barrier could reach memory
+    // before a late sibling's load -- that wavefront would see n == 0, take the scan path and leave the others alone at the
+    // barriers of the chain.  NO store to the hint slots may be placed in front of this barrier.
+    if ((int)threadIdx.x < kHintJobs) myhints[threadIdx.x] = make_uint2(0u, 0u);   // taken
     // ---- the chain, one lane per slot ----
     StageMap m;
     uint32_t episode = 0;
@@ -1402,19 +1480,44 @@ __device__ __forceinline__ void stage_ahead(const MultiParams &p, const StepExtr
 #ifndef UAVX_EXB
 #define UAVX_EXB 8
 #endif
+#ifndef UAVX_EX8B
+#define UAVX_EX8B 8    // the 8-UAV specialisation: 65 536 x 8 is exactly 8 wavefronts per SIMD
+#endif
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
+__global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 8 ? UAVX_EX8B : 1))) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
                                                             int evaluate, float *__restrict__ obs_out,
-                                                            float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
+                                                            float *__restrict__ rew_out_arg, uint8_t *__restrict__ done_out_arg) {
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
     const int N = NT ? NT : p.N;
+    // Register-tight variants (one resident round of 8 192 wavefronts needs 8 per SIMD: 64 VGPRs and 80 SGPRs): the pointers
+    // that the END of the kernel stores through are fetched again there (LATE) instead of living in scalar registers across
+    // the step -- bounded to 8 wavefronts per SIMD the compiler otherwise parks them in VGPR lanes (v_writelane / v_readlane
+    // in the hot path: 65 536 x 8 fused 13.9 -> 15.5 us in round 3).
+    constexpr bool kTight = (EXT || NT == 8) && W == 1;
+    constexpr int kLate = kTight ? UAVX_LATE_EX : 0;   // LATE() sites of this variant
+    constexpr bool kLateR = (kLate & 8) != 0;
     {
         // the staging workgroups of the launch: [stage_first, stage_first + pf_blocks) -- in front of the env-workgroups or
         // behind them (uavx_step_ex picks; one unsigned compare serves both)
         const uint32_t sb = blockIdx.x - x.stage_first;
         if (sb < x.pf_blocks) {   // uniform per workgroup
-            stage_ahead<NT, EXT, W>(p, x, lds, sb);
+            // The staging path reads its arguments through the laundered segment pointer: left to itself the compiler hoists THOSE scalar loads in
+            // front of this branch, into the prologue of every step wavefront, and with 80 SGPRs parks them in VGPR lanes
+            // there (20 v_writelane at the top of step_ex_kernel<8>).
+#ifndef UAVX_STAGE_LAUNDER
+#define UAVX_STAGE_LAUNDER 1     // 0: off, 1: the 8-UAV specialisation, 2: also the variants with bodies / levels, 3: every variant
+#endif
+            // (A/B, profiles/r04_ab_notes.md: 65 536 x 8 fused 13.95 -> 13.55 us; with bodies no change in time and 2 -> 15
+            //  scalars parked in VGPR lanes elsewhere, so not there; 4 UAVs 7.02 -> 7.11: not there either)
+            if constexpr (UAVX_LATE && W == 1 && ((UAVX_STAGE_LAUNDER >= 1 && NT == 8 && !EXT) || (UAVX_STAGE_LAUNDER >= 2 && EXT) || UAVX_STAGE_LAUNDER >= 3)) {
+                typedef const __attribute__((address_space(4))) MultiParams KP;
+                typedef const __attribute__((address_space(4))) StepExtra KX;
+                const karg_ptr ka = late_kargs();
+                stage_ahead<NT, EXT, W>(*(KP *)ka, *(KX *)(ka + sizeof(MultiParams)), lds, sb);
+            } else {
+                stage_ahead<NT, EXT, W>(p, x, lds, sb);
+            }
             return;
         }
     }
@@ -1457,6 +1560,13 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         // Everything the parked layout consists of is requested together with its tag, before the tag is looked at: the
         // wavefront is one memory round trip behind its mates instead of five (record -> tag -> agents -> bodies, trip by
         // trip), and a launch is as long as its slowest wavefront.
+        // (what only this branch needs from the kernel arguments -- seed, staging arrays -- is fetched here, LATE())
+        LATE_BASE(kLateR, ka);
+        const uint32_t seed_lo = LATE_X_AT(kLateR, ka, x, seed_lo), seed_hi = LATE_X_AT(kLateR, ka, x, seed_hi);
+        const uint4 *const stage_tag = LATE_AT(kLateR, ka, p, stage_tag);
+        const float4 *const stage_agent = LATE_AT(kLateR, ka, p, stage_agent);
+        const float2 *const stage_bpos = EXT ? LATE_AT(kLateR, ka, p, stage_bpos) : nullptr;
+        const float4 *const stage_bleg = EXT ? LATE_AT(kLateR, ka, p, stage_bleg) : nullptr;
         bool hit = false;
         uint4 tag = make_uint4(0, 0, 0, 0);
         float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1465,18 +1575,18 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         // the parked layout of episode `episode` lives in slot episode & 1 of the (slot-major) staging arrays
         const uint32_t sl = episode & 1u;
         const uint32_t sbase = sl * (uint32_t)p.E * (uint32_t)p.B + m.e * (uint32_t)p.B;   // first staged body of this env
-        if (do_reset && x.use_stage) {
-            tag = p.stage_tag[sl * (uint32_t)p.E + m.e];
-            st = p.stage_agent[sl * (uint32_t)p.E * (uint32_t)N + m.a];
+        if (do_reset && LATE_X_AT(kLateR, ka, x, use_stage)) {
+            tag = stage_tag[sl * (uint32_t)p.E + m.e];
+            st = stage_agent[sl * (uint32_t)p.E * (uint32_t)N + m.a];
             if (EXT) {   // the first two body trips (all of them up to B = 2 L); further ones below
-                if (m.i < p.B) { bq0 = p.stage_bpos[sbase + (uint32_t)m.i]; bl0 = p.stage_bleg[sbase + (uint32_t)m.i]; }
-                if (N + m.i < p.B) { bq1 = p.stage_bpos[sbase + (uint32_t)(N + m.i)]; bl1 = p.stage_bleg[sbase + (uint32_t)(N + m.i)]; }
+                if (m.i < p.B) { bq0 = stage_bpos[sbase + (uint32_t)m.i]; bl0 = stage_bleg[sbase + (uint32_t)m.i]; }
+                if (N + m.i < p.B) { bq1 = stage_bpos[sbase + (uint32_t)(N + m.i)]; bl1 = stage_bleg[sbase + (uint32_t)(N + m.i)]; }
             }
-            hit = stage_hit(tag, stage_want<EXT>(p, m.e, episode, x.seed_lo, x.seed_hi));
+            hit = stage_hit(tag, stage_want<EXT>(p, m.e, episode, seed_lo, seed_hi));
         }
         const uint32_t hit_lvl = tag.w & 0xFFu;
         if (EXT && hit) {   // the bodies of a parked layout: staged -> live, and into the env's LDS rows (frees their registers first)
-            if (m.i == 0) p.lvl_cur[m.e] = (uint8_t)hit_lvl;
+            if (m.i == 0) LATE_AT(kLateR, ka, p, lvl_cur)[m.e] = (uint8_t)hit_lvl;
             auto place = [&](int k, float2 q, float4 leg) {
                 const int b = k * N + m.i;
                 if (b < p.B) {
@@ -1493,7 +1603,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
             for (int k = 2; k < p.kb; k++) {
                 const int b = k * N + m.i;
                 const uint32_t gi = sbase + (uint32_t)min(b, p.B - 1);
-                place(k, p.stage_bpos[gi], p.stage_bleg[gi]);
+                place(k, stage_bpos[gi], stage_bleg[gi]);
             }
         }
 #ifndef UAVX_X_NOMISS
@@ -1505,7 +1615,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
             // memory round trip on that (rare) wavefront instead of 10 registers on every wavefront of every launch.
             const bool draw = do_reset && !hit;
             AgentRegs t = {};
-            reset_envs_wave<NT, EXT>(p, m, lds, draw, episode, x.seed_lo, x.seed_hi, t, p.body_pos, p.body_leg, p.lvl_cur);
+            reset_envs_wave<NT, EXT>(p, m, lds, draw, episode, seed_lo, seed_hi, t, p.body_pos, p.body_leg, LATE_AT(kLateR, ka, p, lvl_cur));
             asm volatile("" ::: "memory");   // (the loads below must not be folded into the ones at the top)
             AgentRegs r = {};
             ax = 0.0; ay = 0.0;
@@ -1542,8 +1652,8 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
     uint32_t dn, re, ce;
     // a freshly re-initialised env draws its bodies' waypoints with the episode index `episode`, a running one with the
     // index its own reset used (one less than the stored one)
-    step_agent<NT, EXT>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset, steps_v,
-                        (episode - (do_reset ? 0u : 1u)) & ~kRecEnded);
+    step_agent<NT, EXT, LDS, (kLate & 2) != 0>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, do_reset, steps_v,
+                                               (episode - (do_reset ? 0u : 1u)) & ~kRecEnded);
     // episode end test for the NEXT call (test_sac_multi.py:67,112,116)
     bool all_done;
     if (W == 1) {
@@ -1567,9 +1677,22 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
     // agent of write-through stores drain underneath it.  (The tile never overlaps the theta rows the score sum below reads:
     // separate arrays, or -- with scripted bodies -- the first 2 560 B of a union whose theta rows start at byte 3 072.)
     store_obs_block<NT>(p, m, lds, o, obs_out);
+    float2 *pos_p = p.pos;
+    double2 *vel_p = p.vel;
+    Goal *goal_p = p.goal;
+    uint4 *rec_p = p.env_rec;
+    uint32_t *wsteps_p = p.wave_steps;
+    float *rew_out = rew_out_arg;
+    uint8_t *done_out = done_out_arg;
+    if constexpr (kLateR && UAVX_LATE) {
+        LATE_BASE(true, kt);
+        pos_p = LATE_AT(true, kt, p, pos); vel_p = LATE_AT(true, kt, p, vel); goal_p = LATE_AT(true, kt, p, goal);
+        rec_p = LATE_AT(true, kt, p, env_rec); wsteps_p = LATE_AT(true, kt, p, wave_steps);
+        rew_out = late_karg<float *>(kIoRew, kt); done_out = late_karg<uint8_t *>(kIoDone, kt);
+    }
     if (m.active) {
-        if (!(EXT && (s.flags & kFlagInactive))) store_agent(p, m.a, s, flags_in);
-        else if (do_reset) { p.pos[m.a] = make_float2(s.x, s.y); p.vel[m.a] = make_double2(0.0, 0.0); }  // parked at +inf
+        if (!(EXT && (s.flags & kFlagInactive))) store_agent(p, pos_p, vel_p, goal_p, m.a, s, flags_in);
+        else if (do_reset) { pos_p[m.a] = make_float2(s.x, s.y); vel_p[m.a] = make_double2(0.0, 0.0); }  // parked at +inf
         rew_out[m.a] = rew;
         // episode end test for the NEXT call (test_sac_multi.py:67,112,116); meaningful in the env's first lane
         const uint32_t steps_next = do_reset ? 0u : steps_v + 1u;
@@ -1583,25 +1706,27 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
         uint32_t dbyte = dn;
         if (x.flags_in_done && m.i == 0) dbyte |= (do_reset ? 2u : 0u) | (ended ? 4u : 0u) | ((ended && !terminal) ? 8u : 0u);
         done_out[m.a] = (uint8_t)dbyte;
-        if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
-        if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
-        if (!(fabsf(rew) < INFINITY)) atomicAdd(&p.nonfin[m.e], 1u);
-        if (m.lane == 0) p.wave_steps[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
+        if (re) atomicAdd(&LATE(kLate & 1, p, reach)[m.e], 1u);                // MUW:221
+        if (ce) atomicAdd(&LATE(kLate & 1, p, coll)[m.e], 1u);                 // MUW:209
+        if (!(fabsf(rew) < INFINITY)) atomicAdd(&LATE(kLate & 1, p, nonfin)[m.e], 1u);
+        if (m.lane == 0) wsteps_p[m.wave] = wave_count + 1u;  // single writer: this wave (MUW:238)
         if (m.i == 0) {
             // With scripted bodies the env record is read AGAIN here by the one lane that rewrites it, instead of being
             // carried through the step in four registers of every lane (nothing has written it since the load at the top of
             // the launch): that kernel fits 64 VGPRs that way, i.e. 8 wavefronts per SIMD and ONE resident round for the
             // 8 192 wavefronts of a 65 536-env launch.  The other variants have registers to spare and keep it.
-            const uint4 rec = EXT ? p.env_rec[m.e] : rec0;
+            const uint4 rec = (EXT || NT == 8) ? rec_p[m.e] : rec0;
             float2 run = do_reset ? make_float2(0.f, 0.f) : make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w));
-            if (!x.flags_in_done) {
-                if (x.reset_mask) x.reset_mask[m.e] = do_reset ? 1 : 0;
-                if (x.ended) x.ended[m.e] = ended ? 1 : 0;
-                if (x.truncated) x.truncated[m.e] = (ended && !terminal) ? 1 : 0;
+            if (!x.flags_in_done) {   // (three pointers nobody needs before this line: fetched here)
+                uint8_t *const rm = LATE_X(kLateR, x, reset_mask), *const en = LATE_X(kLateR, x, ended), *const tr = LATE_X(kLateR, x, truncated);
+                if (rm) rm[m.e] = do_reset ? 1 : 0;
+                if (en) en[m.e] = ended ? 1 : 0;
+                if (tr) tr[m.e] = (ended && !terminal) ? 1 : 0;
             }
             uint4 out = rec;
             if (do_reset) {  // fold the ended episode, start the new one: steps == 0 after this launch (MUW:166)
-                fold_store(p, m.e, wave_count - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)), fold_load(p, m.e));
+                fold_store<(kLate & 4) != 0>(p, m.e, wave_count - rec.x, make_float2(__uint_as_float(rec.z), __uint_as_float(rec.w)),
+                                             fold_load<(kLate & 4) != 0>(p, m.e));
                 out.x = wave_count + 1u;
                 out.y = episode + 1u;
             }
@@ -1613,7 +1738,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_EXB : 1) void ste
                 run.y += score;
             }
             out.z = __float_as_uint(run.x); out.w = __float_as_uint(run.y);
-            if (out.x != rec.x || out.y != rec.y || out.z != rec.z || out.w != rec.w) p.env_rec[m.e] = out;
+            if (out.x != rec.x || out.y != rec.y || out.z != rec.z || out.w != rec.w) rec_p[m.e] = out;
         }
     }
 #ifdef UAVX_STAMPS
@@ -2732,6 +2857,16 @@ int uavx_load(uavx_handle *h, const void *src, void *stream) {
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: not a snapshot of this library version");
     if (hd.E != h->p.E || hd.N != h->p.N || hd.B != h->p.B || hd.slab_bytes != h->slab_bytes)
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: the snapshot was taken from a handle of another shape (envs / agents / bodies)");
+    // everything else the header carries goes into copy lengths, kernel arguments and table indices: a truncated or damaged
+    // snapshot is refused here, not found out by a kernel
+    const bool lvl_ok = hd.n_levels >= 0 && hd.n_levels <= UAVX_MAX_LEVELS &&
+                        (hd.n_levels == 0 ? (hd.level_lo == -1 && hd.level_hi == -1)
+                                          : (hd.level_lo < 0 || (hd.level_lo <= hd.level_hi && hd.level_hi < hd.n_levels)));
+    if ((hd.wide != 0 && hd.wide != 1) || (hd.ext != 0 && hd.ext != 1) || hd.wide_bytes != (hd.wide ? wide_slab_bytes(h) : 0) ||
+        !lvl_ok || hd.prefetch_every < 0 || hd.env_offset < 0 || !config_valid(&hd.cfg) || hd.cfg.num_agents != h->p.N ||
+        hd.cfg.num_bodies != h->p.B || !(hd.rule.speed >= 0) || hd.rule.period < 1 || (hd.rule.period & (hd.rule.period - 1)) != 0 ||
+        (hd.ext == 0 && (hd.B > 0 || hd.n_levels > 0)) || (hd.wide && hd.ext))
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: inconsistent snapshot header (truncated or corrupted snapshot)");
     const char *b = static_cast<const char *>(src);
     if (hd.wide) {   // the float64-position arrays exist from the first switch to that mode on
         const int rc = uavx_set_position_mode(h, UAVX_POS_F64, stream);

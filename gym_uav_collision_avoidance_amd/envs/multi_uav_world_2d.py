@@ -85,7 +85,9 @@ class MultiUAVWorld2D:
         return {"distance": 0}  # MUW:111-114
 
     def _obs_list(self, obs):
-        o = obs[0].cpu().numpy()
+        """N arrays of shape (10,), dtype float64 like the reference's `np.array([...python floats...])` (MUW:98-109); the
+        values are the kernel's float32 ones, widened exactly."""
+        o = obs[0].cpu().numpy().astype(np.float64)
         return [o[i].copy() for i in range(self.num_agents)]
 
     def _draw_layout(self):
@@ -136,7 +138,7 @@ class MultiUAVWorld2D:
         self._host.copy_(self._pack, non_blocking=True)
         torch.cuda.current_stream(self._batched.device).synchronize()
         h = self._host_np
-        obs = h[: n * 40].view(np.float32).reshape(n, 10)
+        obs = h[: n * 40].view(np.float32).reshape(n, 10).astype(np.float64)   # MUW:98-109 returns float64 arrays
         rew = h[n * 40: n * 44].view(np.float32)
         done = h[n * 44: n * 45]
         return ([obs[i].copy() for i in range(n)], [float(r) for r in rew], [bool(d) for d in done], self._get_info())

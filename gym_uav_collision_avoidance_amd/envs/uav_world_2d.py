@@ -56,7 +56,7 @@ class UAVWorld2D:
         episode = int(self._batched.get_state()["counters"][0, 1].item()) + 1
         self._batched.set_state(loc=loc[None], vel=vel.astype(np.float64)[None], tgt=tgt[None], init_d=[init_d],
                                 prev_d=[init_d], flags=[_lib.FLAG_VEL_F32], counters=[[0, episode]])
-        obs = self._batched.observe()[0].cpu().numpy().copy()
+        obs = self._batched.observe()[0].cpu().numpy().astype(np.float64)   # UW:106-111: a float64 array(4,)
         return (obs, self._get_info()) if return_info else obs
 
     def step(self, action):  # UW:137
@@ -72,7 +72,7 @@ class UAVWorld2D:
         self._host.copy_(p, non_blocking=True)
         torch.cuda.current_stream(b.device).synchronize()
         h = self._host_np
-        return (h[:16].view(np.float32).copy(), np.float32(h[16:20].view(np.float32)[0]), bool(h[24]),
+        return (h[:16].view(np.float32).astype(np.float64), np.float32(h[16:20].view(np.float32)[0]), bool(h[24]),
                 {"distance": np.float32(h[20:24].view(np.float32)[0])})
 
     def render(self, mode="human"):  # UW:175 — no-op on a headless node

@@ -22,7 +22,10 @@ setup(
     version="0.1.0",
     description="MI355X-native batched implementation of the gym_uav_collision_avoidance step/reset path",
     packages=find_packages(include=["gym_uav_collision_avoidance_amd", "gym_uav_collision_avoidance_amd.*"]),
-    package_data={"gym_uav_collision_avoidance_amd": ["csrc/*.so", "csrc/*.hip", "csrc/*.hpp", "csrc/Makefile"]},
+    # compat/: the opt-in alias package `gym_uav_collision_avoidance` (install_alias()); shipped as data, never a top-level package
+    package_data={"gym_uav_collision_avoidance_amd": ["csrc/*.so", "csrc/*.hip", "csrc/*.hpp", "csrc/Makefile",
+                                                      "compat/gym_uav_collision_avoidance/*.py",
+                                                      "compat/gym_uav_collision_avoidance/envs/*.py"]},
     install_requires=["numpy", "torch"],
     cmdclass={"build_py": BuildWithHip},
 )

@@ -52,10 +52,17 @@ def test_driver_sized_run_is_a_pure_graph_replay():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 1
+    # the line says what THIS run stepped: the note carries the real ages of the world, not a constant
+    assert d["world_age"]["wall_regions"] == [8, 108] and d["world_age"]["event_regions"] == [108, 108 + 5 * 11 * 20]
+    assert "8-108 launches after its reset" in d["world_note"] and "thousands of steps old" not in d["world_note"]
+    assert d["roofline"]["traffic_measured_in_this_run"] is False and "traffic_note" in d["roofline"]
+    assert d["hsa_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] is not None and "distributed" not in d and "omitted_for_n_gpus>1" not in d
     assert d["steps_executed"] == 3 + 5 + (5 + 5 * 11) * 20    # capture warm-up + warm-up + 5 wall-clock regions of exactly 20 launches + 5 device-time regions (an untimed pass + ten timed ones each: >= 200 launches per event bracket; counted before roofline_steady runs)
     assert d["value"] > 7e9, d["value"]   # 20 x ~6.3 us of kernels + one graph launch; 9-10 G on a quiet box
     ol = d["open_loop_step_k"]            # informational: K steps per launch from an action tape (uavx_step_k), never `value`
-    assert ol["K"] == 32 and ol["tape_out"] and ol["value"] > d["value"] and "valu_frac" in ol
+    assert ol["K"] == 32 and ol["tape_out"] and ol["value"] > d["value"]
+    # counter-derived figures appear exactly when profiles/ holds a PMC pass of THIS build of the kernels (same source hash)
+    assert ("valu_frac" in ol) == ("roofline_valu" in d) == (d["roofline"]["traffic"] is not None)
     st = d["roofline_steady"]             # the same launches over 1000-step regions, next to the 20-step figure
     assert st["steps"] == 1000 and st["frac"] >= 0.93 * d["roofline"]["frac"] and st["kernel_us"] > 3.0   # (box noise; both are pure device time now)
     assert d["roofline"]["kernel_us"] < 1e3 * d["ms_per_step"]   # the wall-clock region holds one graph-launch latency, the event region none
@@ -78,6 +85,7 @@ def test_cfg5_as_designed_line():
 def test_two_rank_rehearsal():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, UAVX_REHEARSAL="1")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)     # an outer launcher that does not export it: the ranks set the default themselves
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
                           "--steps", "200", "--warmup", "20", "--envs", "8192"],
@@ -86,7 +94,8 @@ def test_two_rank_rehearsal():
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["parallelism"] == "env-index shard x2"
     assert abs(d["value"] - 2 * 8192 * 200 / (d["ms_per_step"] * 200 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
-    assert "cpu_baseline" not in d
+    assert "cpu_baseline" not in d and "cpu_baseline" in d["omitted_for_n_gpus>1"]
+    _check_two_ranks(d)
     assert d["steps_executed"] == 3 + 20 + 15 * 200       # capture warm-up + warm-up + 5 wall-clock and 5 device-time regions (an untimed + a timed pass each)
     assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"])   # ... on every env of both shards
 
@@ -96,7 +105,7 @@ def test_gpus_2_without_a_launcher():
     torch.distributed.run: bench.py starts its two ranks itself (child process, before any GPU call in the parent),
     rank 0's line comes through on stdout, exit code 0.  (Rehearsal: both ranks share the one GPU and talk over gloo.)"""
     env = dict(os.environ, UAVX_REHEARSAL="1")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "8192"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
@@ -107,6 +116,26 @@ def test_gpus_2_without_a_launcher():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["envs_per_gpu"] == 8192
     assert d["config"]["parallelism"] == "env-index shard x2" and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+    _check_two_ranks(d)
+    # no --envs given: the hint about configs[3] goes to stderr, the line's tag is computed from what ran
+    out2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "131072", "--no-large"],
+                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out2.returncode == 0, out2.stderr[-3000:]
+    d2 = _last_json(out2.stdout)
+    assert "configs[3]" in d2["config"]["workload"] and d2["config"]["envs_per_gpu"] == 131072   # 2 x 131 072 = the 262 144 envs of configs[3]
+    _check_two_ranks(d2)
+
+
+def _check_two_ranks(d):
+    """The N > 1 line proves what it ran on: two ranks seen by the process group, a time per rank, the same HSA environment in
+    both launch forms (an outer torchrun and bench.py's own launcher)."""
+    g = d["distributed"]
+    assert g["ranks_seen"] == 2 and g["backend"] == "gloo" and g["rehearsal_shared_gpu"] is True
+    assert len(g["per_rank"]) == 2 and [r["rank"] for r in g["per_rank"]] == [0, 1]
+    assert len(g["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in g["per_rank_ms_per_step"])
+    assert d["ms_per_step"] >= 0.999 * min(g["per_rank_ms_per_step"])     # the line's time is the slowest rank's, region by region
+    assert {r["hsa_enable_ipc_mode_legacy"] for r in g["per_rank"]} == {d["hsa_env"]["HSA_ENABLE_IPC_MODE_LEGACY"]} == {"0"}
+    assert len({r["pid"] for r in g["per_rank"]}) == 2
 
 
 def test_rccl_code_path_with_one_rank():
@@ -122,3 +151,6 @@ def test_rccl_code_path_with_one_rank():
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["config"]["mode"] == "graph", (d["config"], out.stderr[-1500:])
     assert d["episode_metrics"]["mean_steps"] == float(d["steps_executed"]) == 3023.0
+    g = d["distributed"]
+    assert g["ranks_seen"] == 1 and g["backend"] == "nccl" and g["rccl_version"] and g["rehearsal_shared_gpu"] is False
+    assert g["distinct_devices"] == 1 and g["per_rank"][0]["name"] and len(g["per_rank_ms_per_step"]) == 1

@@ -688,3 +688,36 @@ def test_largest_supported_batch_addresses_correctly(amd):
         assert torch.equal(sb[k][E - tail:], ss[k]), k
     assert torch.equal(sb["counters"][E - tail:, :3], ss["counters"][:, :3])
     big.close(); small.close()
+
+
+def test_body_trajectories_against_independent_arithmetic_on_device(amd):
+    """The device against arithmetic that comes from neither the oracle nor the HIP source (tests/golden_util.py: Philox4x32-10
+    from its published definition, leg records and positions in numpy float32 from the text of include/uavx.h): three legs of
+    every body, positions / displacements / leg counts bit for bit, headings to float32 accuracy.  The CPU twin of this test
+    (tests/test_oracle_ext.py) holds the oracle to the same arithmetic."""
+    import torch
+    from golden_util import body_track
+    L, B, E, period, speed, seed, off = 3, 5, 6, 8, 6.5, 0x1234567890, 7
+    xs, ys = 44.0, 36.0
+    env = amd.BatchedMultiUAVWorld2D(E, num_agents=L, num_bodies=B, x_size=xs, y_size=ys, body_speed=speed, body_period=period,
+                                     body_seed=seed, env_offset=off, seed=11)
+    env.reset()
+    rec0 = _np(env.get_bodies())
+    episode = int(_np(env.metrics())[0, 3]) - 1
+    steps = 3 * period + 2
+    want = {(e, b): body_track(rec0[e, b, :2], off + e, L + b, episode, seed, xs, ys, speed, 0.02, period, steps)
+            for e in range(E) for b in range(B)}
+    for (e, b), (_, legs) in want.items():
+        _, dx, dy, n, heading, _, _ = legs[0]
+        assert rec0[e, b, 2] == dx and rec0[e, b, 3] == dy and rec0[e, b, 5] == n, (e, b, rec0[e, b], legs[0])
+        assert abs(float(rec0[e, b, 4]) - heading) <= 4e-7 * max(1.0, abs(heading))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for t in range(steps):
+        env.step((torch.rand((E, L, 2), generator=g) * 6 - 3).to(env.device))
+        rec = _np(env.get_bodies())
+        for (e, b), (track, legs) in want.items():
+            np.testing.assert_array_equal(rec[e, b, :2], track[t], err_msg=f"step {t} env {e} body {b}")
+            cur = [l for l in legs if l[0] <= t][-1]
+            assert rec[e, b, 2] == cur[1] and rec[e, b, 3] == cur[2] and rec[e, b, 5] == cur[3], (t, e, b)
+            assert abs(float(rec[e, b, 4]) - cur[4]) <= 4e-7 * max(1.0, abs(cur[4]))
+    env.close()

@@ -203,6 +203,24 @@ def test_snapshot_restores_a_running_batch_exactly(amd, n, bodies, tmp_path):
     small = amd.BatchedMultiUAVWorld2D(E // 2, **kw)
     with pytest.raises(ValueError):
         small.load_state_dict(sd)
+    # a truncated or damaged snapshot is refused before anything is copied (header fields feed copy lengths, kernel arguments
+    # and level-table indices), and the refused handle still runs
+    cut = dict(sd, snapshot=sd["snapshot"][: sd["snapshot"].numel() // 2].clone())
+    with pytest.raises(ValueError):
+        fresh.load_state_dict(cut)
+    import struct
+    for off, fmt, bad in ((24, "<Q", 1 << 40),      # wide_bytes: would be the length of a device-to-device copy
+                          (64, "<i", 99),           # n_levels: indexes the level table
+                          (76, "<i", -5)):          # prefetch_every
+        broken = sd["snapshot"].clone()
+        broken[off:off + struct.calcsize(fmt)] = torch.tensor(list(struct.pack(fmt, bad)), dtype=torch.uint8, device=broken.device)
+        with pytest.raises(ValueError):
+            fresh.load_state_dict(dict(sd, snapshot=broken))
+    fresh.load_state_dict(sd)                       # ... and the handle that refused them is intact
+    fourth = run(fresh, 100, 150)
+    for a, b in zip(first, fourth):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
     fresh.close(); small.close()
 
 

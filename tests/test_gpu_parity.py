@@ -516,13 +516,16 @@ def test_facade_run_multi_call_pattern(amd):
     env = MultiUAVWorld2D(num_agents=num_agent)
     np.random.seed(0)
     observation, info = env.reset(return_info=True)
-    assert info == {"distance": 0}
+    assert info == {"distance": 0} and observation[0].dtype == np.float64 and observation[0].shape == (10,)
     for _ in range(30):
         n_action = [env.action_space.sample() for _ in range(num_agent)]
         observation, reward, done, info = env.step(n_action)
         env.render()
         assert len(observation) == num_agent and len(reward) == num_agent and len(done) == num_agent
         assert all(isinstance(r, float) for r in reward) and all(isinstance(d, bool) for d in done)
+        # MUW:98-109: float64 arrays of shape (10,) (here: the kernel's float32 values, widened exactly)
+        assert all(o.dtype == np.float64 and o.shape == (10,) for o in observation)
+        assert all((o.astype(np.float32).astype(np.float64) == o).all() for o in observation)
         if done[0]:
             observation, info = env.reset(return_info=True)
     assert env.observation_space.shape == (10,) and env.action_space.shape == (2,)
@@ -532,6 +535,21 @@ def test_facade_run_multi_call_pattern(amd):
     a0.location = np.array([1.5, -2.5])
     assert np.allclose(a0.location, [1.5, -2.5]) and a0.done in (True, False)
     env.close()
+
+
+def test_examples_run_with_the_reference_import_lines(amd):
+    """examples/run_multi.py and examples/run.py keep the reference's own import line (run_multi.py:2, run.py:2:
+    `from gym_uav_collision_avoidance.envs import ...`); the opt-in alias makes it resolve to the MI355X façades."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, args in (("run_multi.py", ["--steps", "40"]), ("run.py", [])):
+        src = open(os.path.join(root, "examples", script)).read()
+        assert "from gym_uav_collision_avoidance.envs import" in src
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, capture_output=True, text=True,
+                             timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+    assert "steps" in out.stdout or "episodes" in out.stdout
 
 
 def test_facade_circular_reset_and_float64_pokes(amd, oracle_mod):
@@ -596,6 +614,7 @@ def test_facade_uw_matches_reference_stream(amd):
     env = UAVWorld2D()
     for r in range(meta["resets"]):
         obs, info = env.reset(return_info=True)
+        assert obs.dtype == np.float64 and obs.shape == (4,)      # UW:106-111
         assert obs_err(obs, data[f"r{r}_obs"], UW_ANGLE_COLS) <= TOL
         assert abs(float(info["distance"]) - float(data[f"r{r}_init_d"])) == 0.0
     # UW rollout from a seeded reset == fixture (reset state there came from the same stream position)
@@ -604,6 +623,7 @@ def test_facade_uw_matches_reference_stream(amd):
     env.reset()
     for t in range(50):
         obs, rew, done, info = env.step(d2["actions"][t])
+        assert obs.dtype == np.float64 and obs.shape == (4,)
         assert obs_err(obs, d2["obs"][t], UW_ANGLE_COLS) <= TOL and bool(done) == bool(d2["done"][t])
     env.close()
 

@@ -420,3 +420,84 @@ def test_source_hash_ignores_comments_and_follows_code(tmp_path, monkeypatch):
     assert _lib.source_hash() == h0
     (csrc / "k.hip").write_text("__global__ void k(int *p) { *p = 2; }\n")
     assert _lib.source_hash() != h0
+    # where a preprocessor directive ends is code
+    assert _lib._code_only("#define A 1\nint x = A;\n") != _lib._code_only("#define A 1 int x = A;\n")
+    assert _lib._code_only("#define A 1   // one\nint x = A;\n") == _lib._code_only("#define   A 1\n\nint x =\n A;\n")
+    # the build recipe belongs to the identity: a changed flag (-ffp-contract decides bit-exactness) or -D knob moves the hash,
+    # a reworded Makefile comment does not; so does an override from the environment
+    (csrc / "k.hip").write_text("__global__ void k(int *p) { *p = 1; }\n")
+    (csrc / "Makefile").write_text("# builds\nHIPFLAGS ?= -O3 -ffp-contract=off   # no FMA\n")
+    h1 = _lib.source_hash()
+    assert h1 != h0
+    (csrc / "Makefile").write_text("# builds the library\nHIPFLAGS ?= -O3 -ffp-contract=off   # exact chains\n")
+    assert _lib.source_hash() == h1
+    (csrc / "Makefile").write_text("# builds\nHIPFLAGS ?= -O3 -ffp-contract=fast\n")
+    assert _lib.source_hash() != h1
+    (csrc / "Makefile").write_text("# builds\nHIPFLAGS ?= -O3 -ffp-contract=off   # no FMA\n")
+    monkeypatch.setenv("HIPFLAGS", "-O3 -DUAVX_EXB=6")
+    assert _lib.source_hash() != h1
+
+
+def test_alias_package_is_opt_in(tmp_path):
+    """`from gym_uav_collision_avoidance.envs import MultiUAVWorld2D` (run_multi.py:2) resolves to the MI355X façade only after
+    install_alias() / UAVX_ALIAS=1; by default the name is not importable from this repo, and an importable reference checkout
+    is never shadowed without force=True."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import importlib.util as u\n"
+            "import gym_uav_collision_avoidance_amd as g\n"
+            "print('default', u.find_spec('gym_uav_collision_avoidance') is not None)\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("UAVX_ALIAS", "PYTHONPATH")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0 and "default False" in out.stdout, out.stderr[-1500:]
+    code2 = code + ("g.install_alias()\n"
+                    "import gym_uav_collision_avoidance, gym_uav_collision_avoidance.envs as e\n"
+                    "from gym_uav_collision_avoidance_amd.envs import MultiUAVWorld2D, UAVWorld2D\n"
+                    "print('same', e.MultiUAVWorld2D is MultiUAVWorld2D and e.UAVWorld2D is UAVWorld2D)\n")
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0 and "same True" in out.stdout, out.stderr[-1500:]
+    out = subprocess.run([sys.executable, "-c", code.replace("print('default'", "import gym_uav_collision_avoidance.envs as e; print('viaenv'")],
+                         capture_output=True, text=True, timeout=300, env=dict(env, UAVX_ALIAS="1"), cwd=str(tmp_path))
+    assert out.returncode == 0 and "viaenv True" in out.stdout, out.stderr[-1500:]
+    # a "real" checkout on the path: refused unless forced
+    fake = tmp_path / "ref" / "gym_uav_collision_avoidance"
+    fake.mkdir(parents=True)
+    (fake / "__init__.py").write_text("REAL = True\n")
+    code3 = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import gym_uav_collision_avoidance_amd as g\n"
+             "try:\n    g.install_alias()\n    print('installed')\nexcept ImportError as e:\n    print('refused')\n"
+             "g.install_alias(force=True)\nimport gym_uav_collision_avoidance as m\nprint('forced', not hasattr(m, 'REAL'))\n"
+             % (ROOT, str(tmp_path / "ref")))
+    out = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0 and "refused" in out.stdout and "forced True" in out.stdout, out.stdout + out.stderr[-1500:]
+
+
+def test_hot_kernels_keep_their_scalars_in_registers():
+    """Code-object metadata of the built library (llvm-readelf --notes through tools/kernel_resources.py; nothing runs).
+    * no step / observe kernel of the float32 path spills a VGPR or touches scratch memory;
+    * the kernels a one-round launch of 8 192 wavefronts depends on fit 8 wavefronts per SIMD: <= 64 VGPRs AND <= 80 SGPRs
+      (800 per SIMD in blocks of 16, plus the trap handler's 16 per wavefront: tools/micro/occupancy.hip measured exactly that);
+    * the headline kernels park no scalar in VGPR lanes; the two kernels of BASELINE configs[4] may hold a few there: the builds
+      without any (late kernel-argument loads at every site) were measured SLOWER -- bare step with bodies 17.4 -> 18.2 us --
+      so the bound is what the faster build has (profiles/r04_ab_notes.md section 1), and a regression past it fails here."""
+    import importlib.util
+    from gym_uav_collision_avoidance_amd import _lib
+    lib = _lib.build()
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = {r["name"]: r for r in kr.kernel_table(lib)}
+    assert len(rows) > 50
+    for name, r in rows.items():
+        if name.startswith(("step_kernel", "step_ex_kernel", "observe_kernel", "uw_step")):
+            assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+    for name in ("step_kernel<1, false, false, 1>", "step_kernel<2, false, false, 1>", "step_kernel<4, false, false, 1>",
+                 "step_kernel<8, false, false, 1>", "step_ex_kernel<4, false, false, 1>", "uw_step_kernel<false>"):
+        assert rows[name]["sgpr_spill_count"] == 0, (name, rows[name])
+    for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<0, false, true, 1>", "step_ex_kernel<8, false, false, 1>"):
+        assert rows[name]["sgpr_spill_count"] <= 8, (name, rows[name])
+    for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<0, false, true, 1>", "step_kernel<8, false, false, 1>",
+                 "step_ex_kernel<8, false, false, 1>", "step_kernel<4, false, false, 1>"):
+        r = rows[name]
+        assert r["waves_per_simd"] == 8 and r["vgpr_count"] <= 64 and r["sgpr_count"] <= 80, (name, r)

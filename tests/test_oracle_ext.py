@@ -93,3 +93,40 @@ def test_extension_invariants(oracle_mod):
     np.testing.assert_array_equal(whole.level, np.concatenate([lo_.level, hi_.level]))
     on = (whole.flags & 32) == 0
     np.testing.assert_array_equal(whole.loc[on], np.concatenate([lo_.loc, hi_.loc])[on])
+
+
+def test_body_trajectories_against_independent_arithmetic(oracle_mod):
+    """A hand check that does not come from the oracle: the waypoint stream (Philox4x32-10 written from its published
+    definition, Random123 known answers first), the leg record and the positions of every body over three legs, computed with
+    numpy float32 operations from the text of include/uavx.h (tests/golden_util.py: body_waypoint / body_leg / body_track).
+    Positions, displacements and leg counts must agree bit for bit; the heading (the build's own polynomial) must be the
+    direction of the displacement to float32 accuracy."""
+    from golden_util import body_track, philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    L, B, E, period, speed, seed, off = 3, 5, 6, 8, 6.5, 0x1234567890, 7
+    xs, ys = 44.0, 36.0
+    o = oracle_mod.OracleMulti(num_envs=E, num_agents=L, num_bodies=B, x_size=xs, y_size=ys, body_speed=speed, body_period=period,
+                               body_seed=seed)
+    o.reset_philox(11, env_offset=off)
+    start = o.body[:, :, :2].copy()
+    episode = int(o.counters[0, 3]) - 1          # the episode index the reset drew with
+    steps = 3 * period + 2
+    want = {(e, b): body_track(start[e, b], off + e, L + b, episode, seed, xs, ys, speed, 0.02, period, steps)
+            for e in range(E) for b in range(B)}
+    for (e, b), (_, legs) in want.items():       # leg 0 is installed by the reset
+        _, dx, dy, n, heading, _, _ = legs[0]
+        rec = o.body[e, b]
+        assert rec[2] == dx and rec[3] == dy and rec[5] == n, (e, b, rec, legs[0])
+        assert abs(float(rec[4]) - heading) <= 4e-7 * max(1.0, abs(heading))
+    rng = np.random.default_rng(5)
+    for t in range(steps):
+        o.step(rng.uniform(-3, 3, size=(E, L, 2)), env_offset=off)
+        for (e, b), (track, legs) in want.items():
+            np.testing.assert_array_equal(o.body[e, b, :2], track[t], err_msg=f"step {t} env {e} body {b}")
+            cur = [l for l in legs if l[0] <= t][-1]
+            assert o.body[e, b, 2] == cur[1] and o.body[e, b, 3] == cur[2] and o.body[e, b, 5] == cur[3], (t, e, b)
+            assert abs(float(o.body[e, b, 4]) - cur[4]) <= 4e-7 * max(1.0, abs(cur[4]))
+    assert len(want[(0, 0)][1]) == 4             # legs 0..3 were started

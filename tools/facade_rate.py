@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""BASELINE configs[0]: the LITERAL drop-in -- one env object stepped from a Python loop the way run.py:6-16, run_multi.py:5-23 and
+the trainers (test_sac_multi.py:99) do -- through the single-env façades (H2D of the commands + one launch + one D2H + a stream
+sync per step).  Writes profiles/rNN_facade.json: env-steps/s of UAVWorld2D and MultiUAVWorld2D(num_agents = 1, 4, 5, 8) beside the
+reference's own rate on one core (profiles/*_reference_cpu.json, taken in the build container by tools/time_reference.py; the
+reference cannot run on the GPU box), with the host CPU named.  Same loop as the reference timing: polar U(-1,1)^2 commands
+(test_sac_multi.py:77-80), reset on done[0] or 1500 steps, no render.
+
+    python tools/facade_rate.py r04          (on the GPU box)
+"""
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+SECONDS = float(os.environ.get("UAVX_FACADE_SECONDS", "6"))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def loop(env, n, vmax_norm, multi):
+    rng = np.random.default_rng(1234)
+    np.random.seed(0)
+    env.reset()
+    steps = episodes = t_ep = 0
+    lat = []
+    t0 = time.perf_counter()
+    while True:
+        a = rng.uniform(-1, 1, size=(n, 2))
+        v = (a[:, 0] / 2 + 0.5) * vmax_norm
+        act = np.stack([v * np.cos(a[:, 1] * np.pi), v * np.sin(a[:, 1] * np.pi)], axis=-1)
+        t1 = time.perf_counter()
+        obs, rew, done, info = env.step([act[i] for i in range(n)] if multi else act[0].astype(np.float32))
+        lat.append(time.perf_counter() - t1)
+        steps += 1
+        t_ep += 1
+        if (done[0] if multi else done) or t_ep >= 1500:
+            env.reset()
+            episodes += 1
+            t_ep = 0
+        if steps % 256 == 0 and time.perf_counter() - t0 > SECONDS:
+            break
+    dt = time.perf_counter() - t0
+    lat = np.array(lat[100:]) * 1e6
+    return dict(env_steps_per_s=steps / dt, agent_steps_per_s=steps * n / dt, steps=steps, episodes=episodes,
+                step_call_us_median=float(np.median(lat)), step_call_us_p90=float(np.percentile(lat, 90)),
+                loop_us_per_step=dt / steps * 1e6)
+
+
+def main():
+    import torch
+    from gym_uav_collision_avoidance_amd.envs import MultiUAVWorld2D, UAVWorld2D
+    ref = {}
+    refs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_reference_cpu.json")))
+    ref_meta = None
+    if refs:
+        d = json.load(open(refs[-1]))
+        ref = {(r["world"], r["num_agents"]): r["env_steps_per_s"] for r in d["rows"]}
+        ref_meta = dict(file=os.path.basename(refs[-1]), cpu_model=d.get("cpu_model"), provenance=d.get("provenance"))
+    rows = []
+    for n in (1, 4, 5, 8):
+        env = MultiUAVWorld2D(num_agents=n)
+        r = loop(env, n, float(np.linalg.norm(env.action_space.high)), True)
+        env.close()
+        r.update(world="MultiUAVWorld2D", num_agents=n, reference_env_steps_per_s=ref.get(("MultiUAVWorld2D", n)))
+        rows.append(r)
+    env = UAVWorld2D()
+    r = loop(env, 1, float(np.linalg.norm(env.action_space.high)), False)
+    env.close()
+    r.update(world="UAVWorld2D", num_agents=1, reference_env_steps_per_s=ref.get(("UAVWorld2D", 1)))
+    rows.append(r)
+    for r in rows:
+        if r["reference_env_steps_per_s"]:
+            r["ratio_to_reference"] = r["env_steps_per_s"] / r["reference_env_steps_per_s"]
+    out = dict(rows=rows, host_cpu_model=cpu_model(), host_cpus=os.cpu_count(), gpu=torch.cuda.get_device_name(0),
+               python=sys.version.split()[0], numpy=np.__version__, torch=torch.__version__, seconds_per_row=SECONDS, reference=ref_meta,
+               what="one env per Python call through the drop-in façades: per step one pinned H2D copy of the commands, one step launch, "
+                    "one D2H copy of (obs | reward | done) and a stream synchronize; the Python of the loop itself (command draw, list "
+                    "building) is inside the rate, as it is in the reference's number",
+               note="a façade step is bound by launch-to-done latency (bench.py latency_us) plus two small copies and the Python around "
+                    "them, not by the kernel: the batched surface (BatchedMultiUAVWorld2D / UAVVectorEnv) is what the GPU path is for; "
+                    "the reference's rate falls with num_agents^2 (object-per-agent Python), the façade's does not")
+    path = os.path.join(ROOT, "profiles", f"{tag}_facade.json")
+    json.dump(out, open(path, "w"), indent=1)
+    for r in rows:
+        print(f"{r['world']:16s} N={r['num_agents']}: {r['env_steps_per_s']:9.0f} env-steps/s  step() {r['step_call_us_median']:.1f} us median "
+              f"(reference, 1 core of the build container: {r['reference_env_steps_per_s']})")
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

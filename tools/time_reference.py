@@ -80,7 +80,7 @@ def time_uw(budget_s):
 
 
 rows = []
-for n in (1, 4, 8, 24):
+for n in (1, 4, 5, 8, 24):
     r = time_multi(n, 8.0)
     rows.append(dict(world="MultiUAVWorld2D", num_agents=n, env_steps_per_s=r, agent_steps_per_s=r * n))
     print(f"MultiUAVWorld2D(num_agents={n}): {r:,.0f} env-steps/s", flush=True)
