@@ -329,8 +329,11 @@ def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60)
                 traffic=traffic[0] if traffic else None, traffic_source=traffic[1] if traffic else None,
                 achieved_traffic=(traffic[0] / kernel_s / 1e9) if traffic else None,
                 bytes_per_launch=b, kernel_us=kernel_s * 1e6, envs=E, agents=N, steps=steps,
-                working_set_bytes=ws, note="working set >> 256 MiB Infinity Cache: HBM-resident stream; "
-                                           "achievable HBM rate on MI355X is ~6.3 TB/s (0.79 of the 8 TB/s spec peak)")
+                working_set_bytes=ws, note="working set >> 256 MiB Infinity Cache: HBM-resident stream; achievable HBM rate on MI355X is ~6.3 TB/s "
+                                           "(0.79 of the 8 TB/s spec peak).  Measured separately, not in this run (profiles/r04_ab_notes.md section 4): a "
+                                           "launch of this size writes about as much as the Infinity Cache holds and is still helped by it -- the same "
+                                           "read / write mix streams at 6.05-6.1 TB/s of REAL bytes, flat, from 1 to 4 GB per launch "
+                                           "(tools/micro/stream_mix.hip), and this kernel at 2-4 Mi envs at 0.65-0.69 of the peak in algorithmic bytes")
 
 
 def open_loop_point(E, N, device, gen, K=32, reps=40):

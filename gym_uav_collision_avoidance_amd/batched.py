@@ -663,10 +663,19 @@ class BatchedUAVWorld2D(_Base):
                                          self._stream()), self._h, uw=True)
         return obs
 
-    def step(self, actions):  # UW:137-173
+    def step(self, actions, out=None):  # UW:137-173
+        """out = (obs [E,4] f32, rew [E] f32, done [E] u8 / bool, distance [E] f32): caller-owned device buffers the launch
+        writes into (the single-env façade packs them into one block so that a step is one launch and ONE copy back)."""
         a, code = self._actions_arg(actions, (self.num_envs, 2))
-        obs = self._next_obs_buf()
-        rew, done, info = self._rews[self._flip], self._dones[self._flip], self._infos[self._flip]
+        if out is None:
+            obs = self._next_obs_buf()
+            rew, done, info = self._rews[self._flip], self._dones[self._flip], self._infos[self._flip]
+        else:
+            obs = self._out(out[0], self._obs[0].shape, torch.float32, "out[0]")
+            rew = self._out(out[1], self._rews[0].shape, torch.float32, "out[1]")
+            done = out[2].view(torch.uint8) if out[2].dtype == torch.bool else out[2]
+            done = self._out(done, self._dones[0].shape, torch.uint8, "out[2]")
+            info = self._out(out[3], self._infos[0].shape, torch.float32, "out[3]")
         _lib.check(self._L.uavx_uw_step(self._h, a.data_ptr(), code, obs.data_ptr(), rew.data_ptr(),
                                         done.data_ptr(), info.data_ptr(), self._stream()), self._h, uw=True)
         return obs, rew, done.view(torch.bool), {"distance": info}

@@ -31,8 +31,10 @@ class UAVWorld2D:
         self.clock = None
         # pinned staging for the commands and ONE device->host copy of (obs | rew | info | done) per step
         dev = b.device
-        self._pack = torch.zeros(28, dtype=torch.uint8, device=dev)
-        self._host = torch.zeros(28, dtype=torch.uint8).pin_memory()
+        self._pack = torch.zeros(32, dtype=torch.uint8, device=dev)      # obs 16 B | reward 4 | distance 4 | done 1
+        self._out = (self._pack[:16].view(torch.float32).view(1, 4), self._pack[16:20].view(torch.float32),
+                     self._pack[24:25], self._pack[20:24].view(torch.float32))
+        self._host = torch.zeros(32, dtype=torch.uint8).pin_memory()
         self._host_np = self._host.numpy()
         self._act_host = {np.dtype(np.float32): torch.zeros((1, 2), dtype=torch.float32).pin_memory(),
                           np.dtype(np.float64): torch.zeros((1, 2), dtype=torch.float64).pin_memory()}
@@ -65,11 +67,8 @@ class UAVWorld2D:
         self._act_host[key].numpy()[0] = a
         self._act_dev[key].copy_(self._act_host[key], non_blocking=True)
         b = self._batched
-        obs, rew, done, info = b.step(self._act_dev[key])
-        p = self._pack
-        p[:16].view(torch.float32).copy_(obs[0]); p[16:20].view(torch.float32).copy_(rew)
-        p[20:24].view(torch.float32).copy_(info["distance"]); p[24:25].copy_(done.view(torch.uint8))
-        self._host.copy_(p, non_blocking=True)
+        b.step(self._act_dev[key], out=self._out)        # the launch writes straight into the packed block
+        self._host.copy_(self._pack, non_blocking=True)
         torch.cuda.current_stream(b.device).synchronize()
         h = self._host_np
         return (h[:16].view(np.float32).astype(np.float64), np.float32(h[16:20].view(np.float32)[0]), bool(h[24]),

@@ -11,7 +11,8 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 mkdir -p $OUT
-python3 -c "from gym_uav_collision_avoidance_amd import _lib; import json; json.dump({'csrc_sha': _lib.source_hash()}, open('$OUT/meta.json','w'))"
+# what the passes were taken on: the hash bench.py compares with the loaded library's, and when (the tool writes both; nothing is keyed by hand)
+python3 -c "from gym_uav_collision_avoidance_amd import _lib; import json, datetime; json.dump({'csrc_sha': _lib.source_hash(), 'taken_utc': datetime.datetime.now(datetime.timezone.utc).strftime('%Y-%m-%dT%H:%M:%SZ')}, open('$OUT/meta.json','w'))"
 declare -A PASS
 PASS[fetch]="FETCH_SIZE"
 PASS[write]="WRITE_SIZE"
