@@ -220,7 +220,8 @@ def test_float64_position_mode_vs_oracle_and_back(amd, oracle_mod, n, E):
     env.close()
 
 
-N_CASES = [(1, 3000), (2, 2048), (3, 1000), (4, 4096), (5, 777), (8, 1024), (16, 256), (24, 130), (33, 64), (64, 70)]
+# (1, 4096) is BASELINE configs[1] literally: 4 096 parallel envs x 1 UAV
+N_CASES = [(1, 4096), (2, 2048), (3, 1000), (4, 4096), (5, 777), (8, 1024), (16, 256), (24, 130), (33, 64), (64, 70)]
 
 
 @pytest.mark.parametrize("n,E", N_CASES)
@@ -461,7 +462,7 @@ def test_uw_fixture_replay(amd, name):
 
 
 def test_uw_oracle_random_batch(amd, oracle_mod):
-    E = 5000
+    E = 4096     # BASELINE configs[1] literally (the single-UAV world)
     env = amd.BatchedUAVWorld2D(E, seed=21, env_offset=3)
     orc = oracle_mod.OracleSingle(num_envs=E, nthreads=8)
     obs_g = env.reset()
