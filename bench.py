@@ -241,7 +241,9 @@ class Stepper:
 def event_passes(K):
     """How many back-to-back passes of K launches one device-time region brackets: at least 200 launches, so that the ~10 us
     device-side start of a graph replay -- which rocprofv3's per-kernel average does not contain -- is a small share of the
-    bracket even when K is 20 (the wall-clock regions `value` comes from are exactly K launches, always)."""
+    bracket even when K is 20 (the wall-clock regions `value` comes from are exactly K launches, always).  ONE pass from
+    K = 200 on: an event region then runs 2 K launches (the untimed pass + the timed one), so `--steps 2000` spends
+    5 x 4 000 launches on device time beside the 5 x 2 000 of the wall-clock regions."""
     return max(1, -(-200 // max(1, K)))
 
 
