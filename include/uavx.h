@@ -335,7 +335,10 @@ int uavx_get_nonfinite(uavx_handle *h, uint32_t *counts, void *stream);
  *   uavx_snapshot_bytes  size of the DEVICE buffer a snapshot needs (fixed for a handle).
  *   uavx_save            enqueues the copy on `stream` (device to device; 256-byte aligned buffer); no synchronisation.
  *   uavx_load            the handle must have the shape (envs, agents, bodies) the snapshot was taken from; reads the
- *                        snapshot's header on the host first, so it WAITS for `stream` once, then enqueues the copy. */
+ *                        snapshot's header on the host first, so it WAITS for `stream` once, then enqueues the copy.
+ *                        Every header field that becomes a copy length, a kernel argument or a table index is checked
+ *                        before anything is copied (a truncated or damaged snapshot: UAVX_ERR_INVALID_ARG, handle untouched);
+ *                        the buffer must hold uavx_snapshot_bytes() bytes. */
 int64_t uavx_snapshot_bytes(const uavx_handle *h);
 int uavx_save(uavx_handle *h, void *snapshot, void *stream);
 int uavx_load(uavx_handle *h, const void *snapshot, void *stream);
