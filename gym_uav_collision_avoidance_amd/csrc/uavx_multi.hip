@@ -51,7 +51,7 @@ namespace uavx {
 // LATE(on, p, member): p.member -- with `on` (a compile-time flag of the kernel variant) fetched where it is used instead of
 // at the top of the kernel (late_karg(), uavx_device.hpp): for members that only a rare branch or the last instructions of a
 // wavefront need, in the variants whose scalar registers are tight (8 wavefronts per SIMD = 80 SGPRs).  `p` must be the kernel's
-// FIRST argument (it is, in every kernel of this file).  NOT a free lunch, hence per variant: the headline kernel (4 UAVs, 66
+// FIRST argument -- or, in step_ex_kernel, sit kExLead bytes into the segment (the macros add that).  NOT a free lunch, hence per variant: the headline kernel (4 UAVs, 66
 // SGPRs, nothing to gain) lost 0.34 us of 5.85 with its `prev_ovr` / counter pointers fetched late -- the scalar loads at the top
 // regroup (one dwordx8 became a dwordx2 + a dwordx4) and that launch is latency-shaped (profiles/r04_ab_notes.md).
 // -DUAVX_LATE=0 turns every site off (A/B).
@@ -73,18 +73,17 @@ __device__ __forceinline__ T karg_if(T plain, uint32_t byte_off, karg_ptr ka) {
     if constexpr (ON && UAVX_LATE) return late_karg<T>(byte_off, ka);
     else return plain;
 }
-#define LATE(on, p, member) karg_if<(on)>((p).member, (uint32_t)offsetof(MultiParams, member))
+// (every site that is switched on lives in step_ex_kernel, whose MultiParams sits behind kExLead bytes of leading scalar arguments)
+constexpr uint32_t kExLead = 48;
+#define LATE(on, p, member) karg_if<(on)>((p).member, kExLead + (uint32_t)offsetof(MultiParams, member))
 // several members at one place: `LATE_BASE(on, ka);` once, then LATE_AT(on, ka, p, member) (one laundering point for all of them)
 #define LATE_BASE(on, ka) const karg_ptr ka = kargs_if<(on)>()
-#define LATE_AT(on, ka, p, member) karg_if<(on)>((p).member, (uint32_t)offsetof(MultiParams, member), ka)
+#define LATE_AT(on, ka, p, member) karg_if<(on)>((p).member, kExLead + (uint32_t)offsetof(MultiParams, member), ka)
 // members of uavx_step_ex's options block: the SECOND argument of step_ex_kernel, directly behind the first (static_assert below)
-#define LATE_X(on, x, member) karg_if<(on)>((x).member, (uint32_t)(sizeof(MultiParams) + offsetof(StepExtra, member)))
-#define LATE_X_AT(on, ka, x, member) karg_if<(on)>((x).member, (uint32_t)(sizeof(MultiParams) + offsetof(StepExtra, member)), ka)
-// which sites a variant switches on (bit mask, -DUAVX_LATE_STEP=... for A/B): 1 the counter atomics at the end of a step,
+#define LATE_X(on, x, member) karg_if<(on)>((x).member, kExLead + (uint32_t)(sizeof(MultiParams) + offsetof(StepExtra, member)))
+#define LATE_X_AT(on, ka, x, member) karg_if<(on)>((x).member, kExLead + (uint32_t)(sizeof(MultiParams) + offsetof(StepExtra, member)), ka)
+// which sites a variant of step_ex_kernel switches on (bit mask, -DUAVX_LATE_EX=... for A/B): 1 the counter atomics at the end of a step,
 // 2 a body's new waypoint (stage_bodies), 4 the episode fold, 8 step_ex's re-initialisation block, its tail pointers and flag arrays
-#ifndef UAVX_LATE_STEP
-#define UAVX_LATE_STEP 0      // step_kernel with bodies / levels (one-wavefront workgroups)
-#endif
 #ifndef UAVX_LATE_EX
 #define UAVX_LATE_EX 15       // step_ex_kernel with bodies / levels, and its 8-UAV specialisation
 #endif
@@ -213,8 +212,8 @@ static_assert(sizeof(MultiParams) % alignof(StepExtra) == 0, "LATE_X: StepExtra 
 // alias, and the compiler orders loads against stores on that knowledge -- handing them over in a struct cost the 4-UAV fused
 // launch 0.2 us of 7.0).  Their places in the kernel-argument segment, for the variants that fetch the two output pointers
 // again at their end (LATE_IO): each parameter sits at the next multiple of its alignment.
-constexpr uint32_t kIoBase = (uint32_t)(sizeof(MultiParams) + sizeof(StepExtra));   // const void *actions
-constexpr uint32_t kIoRew = kIoBase + 24, kIoDone = kIoBase + 32;                    // (int evaluate +8, float *obs_out +16,) rew_out, done_out
+constexpr uint32_t kIoBase = kExLead + (uint32_t)(sizeof(MultiParams) + sizeof(StepExtra));   // int evaluate
+constexpr uint32_t kIoRew = kIoBase + 16, kIoDone = kIoBase + 24;                    // (float *obs_out +8,) rew_out, done_out
 static_assert(sizeof(StepExtra) % 8 == 0, "the pointer parameters behind StepExtra start on its end");
 
 struct LaneMap {
@@ -234,34 +233,37 @@ struct LaneMap {
 // packed from thread 0 (so agent slot = a0 + thread id).  W = 1 everywhere except for agent counts that would leave
 // many lanes of a single wavefront idle (N = 24: 48 of 64; three wavefronts hold 8 envs with none idle).
 template <int NT, bool EXT = false, int W = 1>
-__device__ __forceinline__ LaneMap lane_map(const MultiParams &p, uint32_t wave = blockIdx.x) {   // wave: env-workgroup index
+__device__ __forceinline__ LaneMap lane_map_from(uint32_t E, int n_agents, int envs_per_group, int magic, int nslots, uint32_t wave) {
     LaneMap m;
-    const int N = NT ? NT : p.N;
-    const int epw = NT ? (kWave / (NT ? NT : 1)) : p.epw;
+    const int N = NT ? NT : n_agents;
+    const int epw = NT ? (kWave / (NT ? NT : 1)) : envs_per_group;
     m.lane = threadIdx.x;            // thread in its workgroup (= lane for W == 1)
     int g;
     if (NT) {
         g = m.lane / (NT ? NT : 1);
         m.i = m.lane % (NT ? NT : 1);
     } else {
-        g = (m.lane * p.magic) >> 16;  // floor(thread / N) for thread < 256
+        g = (m.lane * magic) >> 16;  // floor(thread / N) for thread < 256
         m.i = m.lane - g * N;
     }
     m.wave = wave;
-    const uint32_t E = (uint32_t)p.E;
     const uint32_t e0 = wave * epw;
     const uint32_t envs_here = e0 < E ? min(E - e0, (uint32_t)epw) : 0u;
     m.e = e0 + g;
     m.active = (uint32_t)g < envs_here;
     m.base = m.active ? (g * N) & (kWave - 1) : 0;  // first lane of the env's group in its wavefront (W == 1: ballot shifts)
     m.g = m.active ? g : 0;
-    m.nslots = EXT ? p.nslots : N;
+    m.nslots = EXT ? nslots : N;
     m.nlearn = N;
     m.rbase = m.active ? g * m.nslots : 0;  // idle lanes still execute the LDS scan: keep it in bounds
     m.a0 = e0 * N;
     m.a = m.a0 + m.lane;            // whole envs are packed from thread 0: slot = a0 + thread
     m.cnt = (int)envs_here * N;
     return m;
+}
+template <int NT, bool EXT = false, int W = 1>
+__device__ __forceinline__ LaneMap lane_map(const MultiParams &p, uint32_t wave = blockIdx.x) {   // wave: env-workgroup index
+    return lane_map_from<NT, EXT, W>((uint32_t)p.E, p.N, p.epw, p.magic, p.nslots, wave);
 }
 
 struct AgentRegs {
@@ -837,49 +839,66 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 }
 
 // One env step per launch (the RL loop's shape: the policy runs between two launches).
+// The arguments the FIRST instructions need -- command pointer, the base of the state allocation and the 32-bit offsets of its
+// arrays, the numbers the lane mapping is made of -- are LEADING SCALAR kernel arguments: gfx950 preloads those into SGPRs before
+// the wavefront starts (Makefile: -mllvm -amdgpu-kernarg-preload-count), so the state loads are the first thing a wavefront does
+// instead of waiting for a scalar load of the argument segment; everything else of the argument struct is fetched behind them
+// (scheduling barrier).  A/B, same library, three runs each (profiles/r04_ab_notes.md section 10): 65 536 x 4 5.76 -> 5.56 us,
+// x 8 10.4 -> 10.0, x 2 4.19 -> 4.09, 32 768 x 4 4.53 -> 4.35.
 // (with bodies the allocator lands on 65 VGPRs = 7 wavefronts per SIMD; asking for 8 gives 62 without a spill)
 #ifndef UAVX_STEPB
 #define UAVX_STEPB 8
 #endif
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void step_kernel(MultiParams p, const void *__restrict__ actions, int evaluate,
-                                                         float *__restrict__ obs_out, float *__restrict__ rew_out,
-                                                         uint8_t *__restrict__ done_out) {
+__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void step_kernel(
+    const void *__restrict__ actions, char *slab, uint32_t off_vel, uint32_t off_goal, uint32_t off_rec, uint32_t off_wsteps,
+    uint32_t num_envs, uint32_t n_agents, uint32_t envs_per_group, uint32_t magic, uint32_t nslots, MultiParams p, int evaluate,
+    float *__restrict__ obs_out, float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
-    const LaneMap m = lane_map<NT, EXT, W>(p);
+    float2 *const pos_b = reinterpret_cast<float2 *>(slab);
+    double2 *const vel_b = reinterpret_cast<double2 *>(slab + off_vel);
+    Goal *const goal_b = reinterpret_cast<Goal *>(slab + off_goal);
+    const LaneMap m = lane_map_from<NT, EXT, W>(num_envs, (int)n_agents, (int)envs_per_group, (int)magic, (int)nslots, blockIdx.x);
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
     uint4 rec = make_uint4(0, 0, 0, 0);
     uint32_t wave_count = 0;
-    if (EXT) {  // the bodies' waypoint schedule runs on the env's step count and episode index
-        // (unconditional, index clamped for idle lanes: loaded under the `active` branch, the arithmetic on the record was
-        // pulled into that branch together with a full wait -- a memory round trip BEFORE the state loads went out)
-        rec = p.env_rec[m.active ? m.e : 0u];
-        wave_count = p.wave_steps[blockIdx.x];
-    }
-    if (m.active) {
-        // the command is requested BEFORE the state: load_agent ends in arithmetic on what it loaded (prev_distance), and a
-        // load placed behind that would start a second memory round trip after the first one has come back
-        load_action<ACT64>(actions, m.a, ax, ay);
-        load_agent(p, m.a, s);
+    {
+        // Unconditional (idle lanes of the last workgroup read slot 0 and drop what they compute): the requests leave in front
+        // of every scalar load of the argument struct.  The command goes first: prev_distance is arithmetic on the state, and
+        // a load placed behind that would start a second memory round trip after the first one has come back.
+        const uint32_t el = m.active ? m.e : 0u, al = m.active ? m.a : 0u;
+        if (EXT) {  // the bodies' waypoint schedule runs on the env's step count and episode index
+            rec = reinterpret_cast<const uint4 *>(slab + off_rec)[el];
+            wave_count = reinterpret_cast<const uint32_t *>(slab + off_wsteps)[blockIdx.x];
+        }
+        load_action<ACT64>(actions, al, ax, ay);
+        const float2 d = pos_b[al];
+        const double2 v = vel_b[al];
+        const Goal g = goal_b[al];
+        __builtin_amdgcn_sched_barrier(0);
+        s.x = d.x; s.y = d.y; s.vx = v.x; s.vy = v.y;
+        s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d; s.flags = g.flags;
+        s.prev_d = natural_prev_d(s.flags, s.x, s.y, s.tx, s.ty);
+        if (m.active && (s.flags & kFlagPrevOvr)) s.prev_d = p.prev_ovr[m.a];  // rare: only after a caller poked the state
     }
     const uint32_t flags_in = s.flags;
     float o[10], rew;
     uint32_t dn, re, ce;
-    constexpr int kLate = (EXT && W == 1) ? UAVX_LATE_STEP : 0;   // LATE() sites of this variant
-    step_agent<NT, EXT, LDS, (kLate & 2) != 0>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, false, wave_count - rec.x,
-                                               ((rec.y & ~kRecEnded) - 1u) & ~kRecEnded);
+    step_agent<NT, EXT, LDS, false>(p, m, lds, s, ax, ay, evaluate, o, rew, dn, re, ce, false, wave_count - rec.x,
+                                    ((rec.y & ~kRecEnded) - 1u) & ~kRecEnded);
     if (m.active) {
-        if (!(EXT && (flags_in & kFlagInactive))) store_agent(p, m.a, s, flags_in);
+        if (!(EXT && (flags_in & kFlagInactive))) store_agent(p, pos_b, vel_b, goal_b, m.a, s, flags_in);
         rew_out[m.a] = rew;
         done_out[m.a] = (uint8_t)dn;
-        if (re) atomicAdd(&LATE(kLate & 1, p, reach)[m.e], 1u);                // MUW:221
-        if (ce) atomicAdd(&LATE(kLate & 1, p, coll)[m.e], 1u);                 // MUW:209
-        if (!(fabsf(rew) < INFINITY)) atomicAdd(&LATE(kLate & 1, p, nonfin)[m.e], 1u);   // the tripwire of test_ddpg_multi.py:114-130, per env
+        if (re) atomicAdd(&p.reach[m.e], 1u);                // MUW:221
+        if (ce) atomicAdd(&p.coll[m.e], 1u);                 // MUW:209
+        if (!(fabsf(rew) < INFINITY)) atomicAdd(&p.nonfin[m.e], 1u);   // the tripwire of test_ddpg_multi.py:114-130, per env
         if (m.lane == 0) {
-            if (EXT) p.wave_steps[m.wave] = wave_count + 1u;   // single writer: this wave (MUW:238)
-            else atomicAdd(&p.wave_steps[m.wave], 1u);         // MUW:238 for every env of this wave (no-return)
+            uint32_t *const ws = reinterpret_cast<uint32_t *>(slab + off_wsteps);
+            if (EXT) ws[m.wave] = wave_count + 1u;             // single writer: this wave (MUW:238)
+            else atomicAdd(&ws[m.wave], 1u);                   // MUW:238 for every env of this wave (no-return)
         }
     }
     store_obs_block<NT>(p, m, lds, o, obs_out);
@@ -1484,14 +1503,27 @@ __device__ __forceinline__ void stage_ahead(const P &p, const X &x, LDS &lds, ui
 #define UAVX_EX8B 8    // the 8-UAV specialisation: 65 536 x 8 is exactly 8 wavefronts per SIMD
 #endif
 template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 8 ? UAVX_EX8B : 1))) void step_ex_kernel(MultiParams p, StepExtra x, const void *__restrict__ actions,
-                                                            int evaluate, float *__restrict__ obs_out,
-                                                            float *__restrict__ rew_out_arg, uint8_t *__restrict__ done_out_arg) {
+__global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 8 ? UAVX_EX8B : 1))) void step_ex_kernel(const void *__restrict__ actions, char *slab, uint32_t off_vel, uint32_t off_goal,
+                                                            uint32_t off_rec, uint32_t off_wsteps, uint32_t num_envs, uint32_t stage_first,
+                                                            uint32_t pf_blocks, uint32_t step_first, MultiParams p, StepExtra x, int evaluate,
+                                                            float *__restrict__ obs_out, float *__restrict__ rew_out_arg,
+                                                            uint8_t *__restrict__ done_out_arg) {
+    // The first ten parameters (kExLead = 48 bytes) are LEADING SCALARS: gfx950 preloads them into SGPRs before the wavefront
+    // starts (see step_kernel), so the staging / step decision and the first loads -- env record, step counter, command,
+    // state -- need no scalar load of the argument segment.  The state arrays are one allocation: its base + 32-bit offsets
+    // (uavx_create checks they fit) instead of five pointers; the END of the kernel stores through the same registers, so the
+    // register-tight variants no longer fetch those pointers a second time.
+    static_assert(kExLead == 2 * sizeof(void *) + 8 * sizeof(uint32_t), "leading scalar arguments of step_ex_kernel");
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
     const int N = NT ? NT : p.N;
-    // Register-tight variants (one resident round of 8 192 wavefronts needs 8 per SIMD: 64 VGPRs and 80 SGPRs): the pointers
-    // that the END of the kernel stores through are fetched again there (LATE) instead of living in scalar registers across
+    float2 *const pos_b = reinterpret_cast<float2 *>(slab);
+    double2 *const vel_b = reinterpret_cast<double2 *>(slab + off_vel);
+    Goal *const goal_b = reinterpret_cast<Goal *>(slab + off_goal);
+    uint4 *const rec_b = reinterpret_cast<uint4 *>(slab + off_rec);
+    uint32_t *const wsteps_b = reinterpret_cast<uint32_t *>(slab + off_wsteps);
+    // Register-tight variants (one resident round of 8 192 wavefronts needs 8 per SIMD: 64 VGPRs and 80 SGPRs): arguments that
+    // only a rare branch or the END of the kernel needs are fetched there (LATE) instead of living in scalar registers across
     // the step -- bounded to 8 wavefronts per SIMD the compiler otherwise parks them in VGPR lanes (v_writelane / v_readlane
     // in the hot path: 65 536 x 8 fused 13.9 -> 15.5 us in round 3).
     constexpr bool kTight = (EXT || NT == 8) && W == 1;
@@ -1500,28 +1532,50 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
     {
         // the staging workgroups of the launch: [stage_first, stage_first + pf_blocks) -- in front of the env-workgroups or
         // behind them (uavx_step_ex picks; one unsigned compare serves both)
-        const uint32_t sb = blockIdx.x - x.stage_first;
-        if (sb < x.pf_blocks) {   // uniform per workgroup
-            // The staging path reads its arguments through the laundered segment pointer: left to itself the compiler hoists THOSE scalar loads in
-            // front of this branch, into the prologue of every step wavefront, and with 80 SGPRs parks them in VGPR lanes
-            // there (20 v_writelane at the top of step_ex_kernel<8>).
+        const uint32_t sb = blockIdx.x - stage_first;
+        if (sb < pf_blocks) {   // uniform per workgroup
+            // The staging path reads its arguments through the laundered segment pointer: left to itself the compiler hoists
+            // THOSE scalar loads in front of this branch, into the prologue of every step wavefront, and with 80 SGPRs parks
+            // them in VGPR lanes there (20 v_writelane at the top of step_ex_kernel<8>).
 #ifndef UAVX_STAGE_LAUNDER
-#define UAVX_STAGE_LAUNDER 1     // 0: off, 1: the 8-UAV specialisation, 2: also the variants with bodies / levels, 3: every variant
+#define UAVX_STAGE_LAUNDER 3     // 0: off, 1: the 8-UAV specialisation, 2: also the variants with bodies / levels, 3: every variant
 #endif
-            // (A/B, profiles/r04_ab_notes.md: 65 536 x 8 fused 13.95 -> 13.55 us; with bodies no change in time and 2 -> 15
-            //  scalars parked in VGPR lanes elsewhere, so not there; 4 UAVs 7.02 -> 7.11: not there either)
+            // (A/B, profiles/r04_ab_notes.md: 65 536 x 8 fused 13.95 -> 13.55 us.  Every variant since the leading arguments
+            //  are preloaded: the branch above is decided from registers, and hoisted staging loads + their wait in front of
+            //  it would hold up the first state loads of every step wavefront again)
             if constexpr (UAVX_LATE && W == 1 && ((UAVX_STAGE_LAUNDER >= 1 && NT == 8 && !EXT) || (UAVX_STAGE_LAUNDER >= 2 && EXT) || UAVX_STAGE_LAUNDER >= 3)) {
                 typedef const __attribute__((address_space(4))) MultiParams KP;
                 typedef const __attribute__((address_space(4))) StepExtra KX;
                 const karg_ptr ka = late_kargs();
-                stage_ahead<NT, EXT, W>(*(KP *)ka, *(KX *)(ka + sizeof(MultiParams)), lds, sb);
+                stage_ahead<NT, EXT, W>(*(KP *)(ka + kExLead), *(KX *)(ka + kExLead + sizeof(MultiParams)), lds, sb);
             } else {
                 stage_ahead<NT, EXT, W>(p, x, lds, sb);
             }
             return;
         }
     }
-    const LaneMap m = lane_map<NT, EXT, W>(p, blockIdx.x - x.step_first);
+    LaneMap m;
+    if constexpr (NT != 0 && W == 1) {   // compile-time agent count: everything the mapping needs is in registers already
+        constexpr int epw = kWave / (NT ? NT : 1);
+        const uint32_t wave = blockIdx.x - step_first;
+        m.lane = threadIdx.x;
+        const int g = m.lane / (NT ? NT : 1);
+        m.i = m.lane % (NT ? NT : 1);
+        m.wave = wave;
+        const uint32_t e0 = wave * epw;
+        const uint32_t envs_here = e0 < num_envs ? min(num_envs - e0, (uint32_t)epw) : 0u;
+        m.e = e0 + g;
+        m.active = (uint32_t)g < envs_here;
+        m.base = m.active ? (g * NT) & (kWave - 1) : 0;
+        m.g = m.active ? g : 0;
+        m.nslots = NT; m.nlearn = NT;
+        m.rbase = m.active ? g * NT : 0;
+        m.a0 = e0 * NT;
+        m.a = m.a0 + m.lane;
+        m.cnt = (int)envs_here * NT;
+    } else {
+        m = lane_map<NT, EXT, W>(p, blockIdx.x - step_first);
+    }
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
@@ -1529,20 +1583,46 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
 #endif
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
-    // The env record is loaded FIRST and the 48 B of agent state after it: vmcnt retires in issue order, so the
+    // The env record is requested FIRST and the 48 B of agent state after it: vmcnt retires in issue order, so the
     // (rare) re-initialisation below can start as soon as the small load is back and runs underneath the
     // state loads of the launch-wide read burst.  The wave's step counter comes through the scalar cache.
+    // Unconditional (idle lanes of the last workgroup read slot 0 and drop what they compute): the requests leave in front of
+    // every scalar load of the argument structs (scheduling barrier below).
     uint4 rec0 = make_uint4(0, 0, 0, 0);
-    if (m.active) rec0 = p.env_rec[m.e];
-    const uint32_t wave_count = p.wave_steps[m.wave];
-    __builtin_amdgcn_sched_barrier(0);
-    if (m.active) {
-        // the command is requested BEFORE the state: load_agent ends in arithmetic on what it loaded (prev_distance), and a
-        // load placed behind that would start a second memory round trip after the first one has come back
-        load_action<ACT64>(actions, m.a, ax, ay);
-        load_agent(p, m.a, s);
+    uint32_t wave_count;
+    if constexpr (kTight) {
+        // (at the 64-VGPR edge the unconditional form below costs a spill: these variants keep the loads under `active`)
+        if (m.active) rec0 = rec_b[m.e];
+        wave_count = wsteps_b[m.wave];
+        __builtin_amdgcn_sched_barrier(0);
+        if (m.active) {
+            load_action<ACT64>(actions, m.a, ax, ay);
+            const float2 d = pos_b[m.a];
+            const double2 v = vel_b[m.a];
+            const Goal g = goal_b[m.a];
+            s.x = d.x; s.y = d.y; s.vx = v.x; s.vy = v.y;
+            s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d; s.flags = g.flags;
+            s.prev_d = natural_prev_d(s.flags, s.x, s.y, s.tx, s.ty);
+            if (s.flags & kFlagPrevOvr) s.prev_d = p.prev_ovr[m.a];
+        }
+    } else {
+        const uint32_t el = m.active ? m.e : 0u, al = m.active ? m.a : 0u;
+        rec0 = rec_b[el];
+        wave_count = wsteps_b[m.wave];
+        // the command is requested BEFORE the state: prev_distance is arithmetic on what was loaded, and a load placed behind
+        // that would start a second memory round trip after the first one has come back
+        load_action<ACT64>(actions, al, ax, ay);
+        const float2 d = pos_b[al];
+        const double2 v = vel_b[al];
+        const Goal g = goal_b[al];
+        __builtin_amdgcn_sched_barrier(0);
+        s.x = d.x; s.y = d.y; s.vx = v.x; s.vy = v.y;
+        s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d; s.flags = g.flags;
+        s.prev_d = natural_prev_d(s.flags, s.x, s.y, s.tx, s.ty);
+        if (m.active && (s.flags & kFlagPrevOvr)) s.prev_d = p.prev_ovr[m.a];  // rare: only after a caller poked the state
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (!m.active) rec0.y = 0u;   // an idle lane holds env 0's record: it must not take part in a re-initialisation
     const bool do_reset = (rec0.y & kRecEnded) != 0;
     const uint32_t episode = rec0.y & ~kRecEnded;
     uint32_t steps_v = wave_count - rec0.x;
@@ -1619,7 +1699,7 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
             asm volatile("" ::: "memory");   // (the loads below must not be folded into the ones at the top)
             AgentRegs r = {};
             ax = 0.0; ay = 0.0;
-            if (m.active) {
+            if (m.active) {   // (rare path: the state arrays through the argument struct, not the preloaded registers)
                 load_action<ACT64>(actions, m.a, ax, ay);
                 if (!do_reset) load_agent(p, m.a, r);
             }
@@ -1641,7 +1721,9 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
             s.init_d = s.prev_d = parked ? INFINITY : norm32(s.tx - s.x, s.ty - s.y);  // MUW:154-155
         }
         if (do_reset) {
-            p.goal[m.a] = Goal{s.tx, s.ty, s.init_d, s.flags};
+            Goal *goal_w = goal_b;
+            if constexpr (kLateR && UAVX_LATE) goal_w = LATE_AT(true, ka, p, goal);
+            goal_w[m.a] = Goal{s.tx, s.ty, s.init_d, s.flags};
             steps_v = 0;                                           // MUW:166
         }
     }
@@ -1677,14 +1759,17 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
     // agent of write-through stores drain underneath it.  (The tile never overlaps the theta rows the score sum below reads:
     // separate arrays, or -- with scripted bodies -- the first 2 560 B of a union whose theta rows start at byte 3 072.)
     store_obs_block<NT>(p, m, lds, o, obs_out);
-    float2 *pos_p = p.pos;
-    double2 *vel_p = p.vel;
-    Goal *goal_p = p.goal;
-    uint4 *rec_p = p.env_rec;
-    uint32_t *wsteps_p = p.wave_steps;
+    float2 *pos_p = pos_b;
+    double2 *vel_p = vel_b;
+    Goal *goal_p = goal_b;
+    uint4 *rec_p = rec_b;
+    uint32_t *wsteps_p = wsteps_b;
     float *rew_out = rew_out_arg;
     uint8_t *done_out = done_out_arg;
     if constexpr (kLateR && UAVX_LATE) {
+        // (register-tight variants: neither the preloaded base + offsets nor the output pointers stay alive across the step --
+        //  the pointers the tail stores through are fetched from the argument struct here; A/B at 65 536 x 8 fused: holding
+        //  the six preloaded registers instead cost 12.7 -> 13.2 us)
         LATE_BASE(true, kt);
         pos_p = LATE_AT(true, kt, p, pos); vel_p = LATE_AT(true, kt, p, vel); goal_p = LATE_AT(true, kt, p, goal);
         rec_p = LATE_AT(true, kt, p, env_rec); wsteps_p = LATE_AT(true, kt, p, wave_steps);
@@ -1983,6 +2068,7 @@ struct uavx_handle {
     int device;
     void *slab;  // one allocation holding every state array
     size_t slab_bytes = 0;
+    uint32_t off_vel = 0, off_goal = 0, off_rec = 0, off_wsteps = 0;   // byte offsets of vel / goal / env_rec / wave_steps in it (pos: 0)
     // float64-position mode (uavx_set_position_mode): arrays allocated on first use
     bool wide = false;
     WideState w = {};
@@ -2102,11 +2188,15 @@ struct StepLaunch {
     float *obs, *rew; uint8_t *done;
     template <int NT, bool EXT, int W> void run() const {
         const dim3 blk(kWave * W);
+        char *slab = static_cast<char *>(h->slab);
+        const MultiParams &q = h->p;
         if (K == 1) {
             if (action_dtype == UAVX_F64)
-                hipLaunchKernelGGL((step_kernel<NT, true, EXT, W>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+                hipLaunchKernelGGL((step_kernel<NT, true, EXT, W>), grid, blk, 0, st, actions, slab, h->off_vel, h->off_goal, h->off_rec, h->off_wsteps,
+                                   (uint32_t)q.E, (uint32_t)q.N, (uint32_t)q.epw, (uint32_t)q.magic, (uint32_t)q.nslots, q, evaluate, obs, rew, done);
             else
-                hipLaunchKernelGGL((step_kernel<NT, false, EXT, W>), grid, blk, 0, st, h->p, actions, evaluate, obs, rew, done);
+                hipLaunchKernelGGL((step_kernel<NT, false, EXT, W>), grid, blk, 0, st, actions, slab, h->off_vel, h->off_goal, h->off_rec, h->off_wsteps,
+                                   (uint32_t)q.E, (uint32_t)q.N, (uint32_t)q.epw, (uint32_t)q.magic, (uint32_t)q.nslots, q, evaluate, obs, rew, done);
         } else if constexpr (!EXT) {
             if (action_dtype == UAVX_F64)
                 hipLaunchKernelGGL((step_k_kernel<NT, true, W>), grid, blk, 0, st, h->p, actions, evaluate, K, tape_out, obs, rew, done);
@@ -2120,10 +2210,14 @@ struct StepExLaunch {
     uavx_handle *h; dim3 grid; hipStream_t st; StepExtra x; const uavx_step_args *a;
     template <int NT, bool EXT, int W> void run() const {
         const dim3 blk(kWave * W);
+        char *slab = static_cast<char *>(h->slab);
+        const uint32_t ov = h->off_vel, og = h->off_goal, orc = h->off_rec, ow = h->off_wsteps, ne = (uint32_t)h->p.E;
         if (a->action_dtype == UAVX_F64)
-            hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+            hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W>), grid, blk, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first, x.pf_blocks,
+                               x.step_first, h->p, x, a->evaluate, a->obs, a->rew, a->done);
         else
-            hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT, W>), grid, blk, 0, st, h->p, x, a->actions, a->evaluate, a->obs, a->rew, a->done);
+            hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT, W>), grid, blk, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first, x.pf_blocks,
+                               x.step_first, h->p, x, a->evaluate, a->obs, a->rew, a->done);
     }
 };
 
@@ -2370,6 +2464,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     const size_t o_sbleg = off;  off = align_up(off + 2 * E * (size_t)B * sizeof(float4), 256);
     const size_t o_stag = off;   off = align_up(off + 2 * E * sizeof(uint4), 256);
     const size_t o_hint = off;   off = align_up(off + ((E + p.epw - 1) / p.epw + 1) * kHintJobs * sizeof(uint2), 256);   // (staging workgroups <= env-workgroups)
+    // step_ex_kernel addresses the state arrays as slab base + 32-bit offsets (leading scalar kernel arguments)
+    static_assert(sizeof(size_t) >= 8, "64-bit host");
+    if (o_pos != 0 || o_wsteps >= (size_t(1) << 32)) { delete h; return UAVX_ERR_UNSUPPORTED; }
+    h->off_vel = (uint32_t)o_vel; h->off_goal = (uint32_t)o_goal; h->off_rec = (uint32_t)o_steps; h->off_wsteps = (uint32_t)o_wsteps;
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     h->slab_bytes = off;

@@ -131,16 +131,30 @@ __device__ __forceinline__ void uw_load_action(const void *__restrict__ actions,
     }
 }
 
+// The pointers the FIRST instructions need and the env count are leading scalar kernel arguments: gfx950 preloads them into SGPRs
+// (Makefile: -mllvm -amdgpu-kernarg-preload-count), so the four loads leave before any scalar load of the argument struct (see
+// step_kernel in uavx_multi.hip).  A/B (profiles/r04_ab_notes.md section 10): 4 096 envs 2.58 -> 2.48 us, 65 536 3.14 -> 3.00,
+// 1 Mi 17.7 -> 16.7 (0.69 -> 0.73 of the HBM figure).
 template <bool ACT64>
-__global__ __launch_bounds__(kBlock) void uw_step_kernel(UwParams p, const void *__restrict__ actions,
-                                                         float4 *__restrict__ obs_out, float *__restrict__ rew_out,
-                                                         uint8_t *__restrict__ done_out, float *__restrict__ info_out) {
+__global__ __launch_bounds__(kBlock) void uw_step_kernel(const void *__restrict__ actions, const float2 *__restrict__ pos_in,
+                                                         const double2 *__restrict__ vel_in, const UwGoal *__restrict__ goal_in,
+                                                         int64_t num_envs, UwParams p, float4 *__restrict__ obs_out,
+                                                         float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
+                                                         float *__restrict__ info_out) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= p.E) return;
+    if (e >= num_envs) return;
     UwRegs s;
     double ax, ay;
-    uw_load_action<ACT64>(actions, e, ax, ay);   // requested before the state: uw_load ends in arithmetic on what it loaded
-    uw_load(p, e, s);
+    uw_load_action<ACT64>(actions, e, ax, ay);   // requested before the state: prev_distance is arithmetic on what was loaded
+    const float2 d2 = pos_in[e];
+    const double2 v = vel_in[e];
+    const UwGoal g = goal_in[e];
+    __builtin_amdgcn_sched_barrier(0);
+    s.x = d2.x; s.y = d2.y;
+    s.vx = v.x; s.vy = v.y;
+    s.tx = g.tx; s.ty = g.ty; s.init_d = g.init_d; s.flags = g.flags;
+    s.prev_d = norm32(s.tx - s.x, s.ty - s.y);
+    if (s.flags & kUwPrevOvr) s.prev_d = p.prev_ovr[e];    // rare: only after a caller poked the state
     const uint32_t flags_in = s.flags;
     float4 obs; float rew, dist; uint32_t dn;
     uw_step_env(p, s, ax, ay, !ACT64, obs, rew, dn, dist);
@@ -485,11 +499,11 @@ int uavx_uw_step(uavx_uw_handle *h, const void *actions, int action_dtype, float
     UW_ENTER(h);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (action_dtype == UAVX_F64)
-        hipLaunchKernelGGL((uw_step_kernel<true>), env_grid(h), dim3(kBlock), 0, st, h->p, actions,
-                           reinterpret_cast<float4 *>(obs), rew, done, info_distance);
+        hipLaunchKernelGGL((uw_step_kernel<true>), env_grid(h), dim3(kBlock), 0, st, actions, h->p.pos, h->p.vel, h->p.goal, (int64_t)h->p.E,
+                           h->p, reinterpret_cast<float4 *>(obs), rew, done, info_distance);
     else
-        hipLaunchKernelGGL((uw_step_kernel<false>), env_grid(h), dim3(kBlock), 0, st, h->p, actions,
-                           reinterpret_cast<float4 *>(obs), rew, done, info_distance);
+        hipLaunchKernelGGL((uw_step_kernel<false>), env_grid(h), dim3(kBlock), 0, st, actions, h->p.pos, h->p.vel, h->p.goal, (int64_t)h->p.E,
+                           h->p, reinterpret_cast<float4 *>(obs), rew, done, info_distance);
     UW_HIP(h, hipGetLastError());
     return UAVX_OK;
 }

@@ -495,8 +495,10 @@ def test_hot_kernels_keep_their_scalars_in_registers():
     for name in ("step_kernel<1, false, false, 1>", "step_kernel<2, false, false, 1>", "step_kernel<4, false, false, 1>",
                  "step_kernel<8, false, false, 1>", "step_ex_kernel<4, false, false, 1>", "uw_step_kernel<false>"):
         assert rows[name]["sgpr_spill_count"] == 0, (name, rows[name])
-    for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<0, false, true, 1>", "step_ex_kernel<8, false, false, 1>"):
+    for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<8, false, false, 1>"):
         assert rows[name]["sgpr_spill_count"] <= 8, (name, rows[name])
+    # (the fused kernel with bodies: a dozen since its leading arguments are preloaded -- and 2 % faster with them, notes section 10)
+    assert rows["step_ex_kernel<0, false, true, 1>"]["sgpr_spill_count"] <= 14, rows["step_ex_kernel<0, false, true, 1>"]
     for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<0, false, true, 1>", "step_kernel<8, false, false, 1>",
                  "step_ex_kernel<8, false, false, 1>", "step_kernel<4, false, false, 1>"):
         r = rows[name]
