@@ -74,7 +74,7 @@ __device__ __forceinline__ T karg_if(T plain, uint32_t byte_off, karg_ptr ka) {
     else return plain;
 }
 // (every site that is switched on lives in step_ex_kernel, whose MultiParams sits behind kExLead bytes of leading scalar arguments)
-constexpr uint32_t kExLead = 48;
+constexpr uint32_t kExLead = 56;
 #define LATE(on, p, member) karg_if<(on)>((p).member, kExLead + (uint32_t)offsetof(MultiParams, member))
 // several members at one place: `LATE_BASE(on, ka);` once, then LATE_AT(on, ka, p, member) (one laundering point for all of them)
 #define LATE_BASE(on, ka) const karg_ptr ka = kargs_if<(on)>()
@@ -1505,18 +1505,20 @@ __device__ __forceinline__ void stage_ahead(const P &p, const X &x, LDS &lds, ui
 template <int NT, bool ACT64, bool EXT, int W>
 __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 8 ? UAVX_EX8B : 1))) void step_ex_kernel(const void *__restrict__ actions, char *slab, uint32_t off_vel, uint32_t off_goal,
                                                             uint32_t off_rec, uint32_t off_wsteps, uint32_t num_envs, uint32_t stage_first,
-                                                            uint32_t pf_blocks, uint32_t step_first, MultiParams p, StepExtra x, int evaluate,
+                                                            uint32_t pf_blocks, uint32_t step_first, uint32_t shape_packed, uint32_t magic,
+                                                            MultiParams p, StepExtra x, int evaluate,
                                                             float *__restrict__ obs_out, float *__restrict__ rew_out_arg,
                                                             uint8_t *__restrict__ done_out_arg) {
-    // The first ten parameters (kExLead = 48 bytes) are LEADING SCALARS: gfx950 preloads them into SGPRs before the wavefront
+    // The first twelve parameters (kExLead = 56 bytes: all 14 dwords the preload takes) are LEADING SCALARS -- shape_packed =
+    // agents | envs per workgroup << 8 | neighbour slots per env << 16 --: gfx950 preloads them into SGPRs before the wavefront
     // starts (see step_kernel), so the staging / step decision and the first loads -- env record, step counter, command,
     // state -- need no scalar load of the argument segment.  The state arrays are one allocation: its base + 32-bit offsets
     // (uavx_create checks they fit) instead of five pointers; the END of the kernel stores through the same registers, so the
     // register-tight variants no longer fetch those pointers a second time.
-    static_assert(kExLead == 2 * sizeof(void *) + 8 * sizeof(uint32_t), "leading scalar arguments of step_ex_kernel");
+    static_assert(kExLead == 2 * sizeof(void *) + 10 * sizeof(uint32_t), "leading scalar arguments of step_ex_kernel");
     using LDS = LdsT<EXT, W>;
     __shared__ LDS lds;
-    const int N = NT ? NT : p.N;
+    const int N = NT ? NT : (int)(shape_packed & 0xFFu);
     float2 *const pos_b = reinterpret_cast<float2 *>(slab);
     double2 *const vel_b = reinterpret_cast<double2 *>(slab + off_vel);
     Goal *const goal_b = reinterpret_cast<Goal *>(slab + off_goal);
@@ -1543,7 +1545,7 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
             // (A/B, profiles/r04_ab_notes.md: 65 536 x 8 fused 13.95 -> 13.55 us.  Every variant since the leading arguments
             //  are preloaded: the branch above is decided from registers, and hoisted staging loads + their wait in front of
             //  it would hold up the first state loads of every step wavefront again)
-            if constexpr (UAVX_LATE && W == 1 && ((UAVX_STAGE_LAUNDER >= 1 && NT == 8 && !EXT) || (UAVX_STAGE_LAUNDER >= 2 && EXT) || UAVX_STAGE_LAUNDER >= 3)) {
+            if constexpr (UAVX_LATE && ((UAVX_STAGE_LAUNDER >= 1 && W == 1 && NT == 8 && !EXT) || (UAVX_STAGE_LAUNDER >= 2 && W == 1 && EXT) || UAVX_STAGE_LAUNDER >= 3)) {
                 typedef const __attribute__((address_space(4))) MultiParams KP;
                 typedef const __attribute__((address_space(4))) StepExtra KX;
                 const karg_ptr ka = late_kargs();
@@ -1554,28 +1556,9 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
             return;
         }
     }
-    LaneMap m;
-    if constexpr (NT != 0 && W == 1) {   // compile-time agent count: everything the mapping needs is in registers already
-        constexpr int epw = kWave / (NT ? NT : 1);
-        const uint32_t wave = blockIdx.x - step_first;
-        m.lane = threadIdx.x;
-        const int g = m.lane / (NT ? NT : 1);
-        m.i = m.lane % (NT ? NT : 1);
-        m.wave = wave;
-        const uint32_t e0 = wave * epw;
-        const uint32_t envs_here = e0 < num_envs ? min(num_envs - e0, (uint32_t)epw) : 0u;
-        m.e = e0 + g;
-        m.active = (uint32_t)g < envs_here;
-        m.base = m.active ? (g * NT) & (kWave - 1) : 0;
-        m.g = m.active ? g : 0;
-        m.nslots = NT; m.nlearn = NT;
-        m.rbase = m.active ? g * NT : 0;
-        m.a0 = e0 * NT;
-        m.a = m.a0 + m.lane;
-        m.cnt = (int)envs_here * NT;
-    } else {
-        m = lane_map<NT, EXT, W>(p, blockIdx.x - step_first);
-    }
+    // (everything the mapping needs arrived in registers with the wavefront)
+    const LaneMap m = lane_map_from<NT, EXT, W>(num_envs, N, (int)((shape_packed >> 8) & 0xFFu), (int)magic,
+                                                (int)(shape_packed >> 16), blockIdx.x - step_first);
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
@@ -2212,12 +2195,13 @@ struct StepExLaunch {
         const dim3 blk(kWave * W);
         char *slab = static_cast<char *>(h->slab);
         const uint32_t ov = h->off_vel, og = h->off_goal, orc = h->off_rec, ow = h->off_wsteps, ne = (uint32_t)h->p.E;
+        const uint32_t shape = (uint32_t)h->p.N | ((uint32_t)h->p.epw << 8) | ((uint32_t)h->p.nslots << 16);   // each <= 192
         if (a->action_dtype == UAVX_F64)
             hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W>), grid, blk, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first, x.pf_blocks,
-                               x.step_first, h->p, x, a->evaluate, a->obs, a->rew, a->done);
+                               x.step_first, shape, (uint32_t)h->p.magic, h->p, x, a->evaluate, a->obs, a->rew, a->done);
         else
             hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT, W>), grid, blk, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first, x.pf_blocks,
-                               x.step_first, h->p, x, a->evaluate, a->obs, a->rew, a->done);
+                               x.step_first, shape, (uint32_t)h->p.magic, h->p, x, a->evaluate, a->obs, a->rew, a->done);
     }
 };
 
@@ -2468,6 +2452,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     static_assert(sizeof(size_t) >= 8, "64-bit host");
     if (o_pos != 0 || o_wsteps >= (size_t(1) << 32)) { delete h; return UAVX_ERR_UNSUPPORTED; }
     h->off_vel = (uint32_t)o_vel; h->off_goal = (uint32_t)o_goal; h->off_rec = (uint32_t)o_steps; h->off_wsteps = (uint32_t)o_wsteps;
+    if (p.epw > 255 || p.nslots > 255) { delete h; return UAVX_ERR_UNSUPPORTED; }   // (packed into one leading argument; <= 64 today)
     e = hipMalloc(&h->slab, off);
     if (e != hipSuccess) { delete h; return UAVX_ERR_ALLOC; }
     h->slab_bytes = off;

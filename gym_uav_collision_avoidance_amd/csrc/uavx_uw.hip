@@ -135,9 +135,12 @@ __device__ __forceinline__ void uw_load_action(const void *__restrict__ actions,
 // (Makefile: -mllvm -amdgpu-kernarg-preload-count), so the four loads leave before any scalar load of the argument struct (see
 // step_kernel in uavx_multi.hip).  A/B (profiles/r04_ab_notes.md section 10): 4 096 envs 2.58 -> 2.48 us, 65 536 3.14 -> 3.00,
 // 1 Mi 17.7 -> 16.7 (0.69 -> 0.73 of the HBM figure).
+// (pos_in / vel_in / goal_in are p.pos / p.vel / p.goal, which the kernel also stores through: not `__restrict__`.  The same
+//  treatment of uw_step_ex_kernel -- record, command and state requested together -- measured no gain: 5.27 vs 5.23 us at 65 536
+//  envs, 24.0 vs 23.3 at 1 Mi; not kept.)
 template <bool ACT64>
-__global__ __launch_bounds__(kBlock) void uw_step_kernel(const void *__restrict__ actions, const float2 *__restrict__ pos_in,
-                                                         const double2 *__restrict__ vel_in, const UwGoal *__restrict__ goal_in,
+__global__ __launch_bounds__(kBlock) void uw_step_kernel(const void *__restrict__ actions, const float2 *pos_in,
+                                                         const double2 *vel_in, const UwGoal *goal_in,
                                                          int64_t num_envs, UwParams p, float4 *__restrict__ obs_out,
                                                          float *__restrict__ rew_out, uint8_t *__restrict__ done_out,
                                                          float *__restrict__ info_out) {
