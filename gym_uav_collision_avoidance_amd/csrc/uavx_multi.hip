@@ -29,6 +29,10 @@
 //   per workgroup: wave_steps[G] (one no-return atomic per launch; env.steps = wave_steps - env_rec.x)
 //   per env:   reach[E] / coll[E] (atomics on the rare events), env_rec[E] (16 B: steps base, episode index,
 //              running returns; touched by reset / step_ex only), episode statistics (fin_*).
+// Kernel arguments: the step kernels take what their FIRST instructions need as leading scalars (command pointer, base of the
+// state allocation + 32-bit array offsets, the numbers of the lane mapping), which gfx950 preloads into SGPRs with the wavefront
+// (Makefile: -mllvm -amdgpu-kernarg-preload-count), and everything else in the by-value MultiParams behind them: the state loads
+// are the first thing a wavefront does (step_kernel, step_ex_kernel; profiles/r04_ab_notes.md section 10).
 // BASELINE configs[4] extension (scripted bodies, per-env curriculum levels; EXT kernel variants): see MultiParams and
 // include/uavx.h; lanes stay one per LEARNER there and the bodies are extra rows of the env's LDS neighbour tile.
 // A body is a position (float2, read + written while it moves) and a leg record {dx, dy, heading, legs} (float4, read
@@ -109,9 +113,9 @@ struct WorldLims {
     float sq_sense, sq_two_r, inv_sense, inv_diag;
 };
 
-// The kernels take this struct BY VALUE: it is their kernel-argument segment, fetched by scalar loads at the top of every
-// wavefront, and a 65 536 x 4 step launch is latency-shaped -- so the ORDER of the members is a tuning
-// parameter, and not an intuitive one.  Measured on one box (profiles/r03_ab_notes.md): a new pointer inserted after `coll`
+// The kernels take this struct BY VALUE: it is (most of) their kernel-argument segment, fetched by scalar loads, and a
+// 65 536 x 4 step launch is latency-shaped -- so the ORDER of the members is a tuning parameter, and not an
+// intuitive one.  (Since round 4 the arguments the first instructions need travel in front of it as preloaded leading scalars.)  Measured on one box (profiles/r03_ab_notes.md): a new pointer inserted after `coll`
 // cost the headline launch 0.35 us of 5.72 with NO other change to the kernel (the members behind it moved across the
 // scalar-load groups the compiler forms, nine loads instead of six sat in front of the first wait); the same pointer appended
 // at the end costs nothing beyond its own use (5.78 with the tripwire it serves); a deliberate "hot members first, one
