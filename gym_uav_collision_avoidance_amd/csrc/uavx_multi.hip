@@ -46,6 +46,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "../../include/uavx.h"
 #include "uavx_device.hpp"
@@ -230,6 +231,7 @@ struct LaneMap {
     uint32_t e, a;   // env, agent slot (E*N < 2^26, checked by uavx_create)
     uint32_t a0;     // first agent slot of this workgroup
     uint32_t wave;   // workgroup index (= index into wave_steps)
+    int obs0;        // first float of this wavefront's obs staging tile in lds.obs (0 unless the workgroup holds several tiles)
     int cnt;         // active agent slots in this workgroup: threads [0, cnt), slots [a0, a0 + cnt)
 };
 
@@ -237,11 +239,12 @@ struct LaneMap {
 // packed from thread 0 (so agent slot = a0 + thread id).  W = 1 everywhere except for agent counts that would leave
 // many lanes of a single wavefront idle (N = 24: 48 of 64; three wavefronts hold 8 envs with none idle).
 template <int NT, bool EXT = false, int W = 1>
-__device__ __forceinline__ LaneMap lane_map_from(uint32_t E, int n_agents, int envs_per_group, int magic, int nslots, uint32_t wave) {
+__device__ __forceinline__ LaneMap lane_map_from(uint32_t E, int n_agents, int envs_per_group, int magic, int nslots, uint32_t wave,
+                                                 uint32_t lane = threadIdx.x, uint32_t tile = 0u) {
     LaneMap m;
     const int N = NT ? NT : n_agents;
     const int epw = NT ? (kWave / (NT ? NT : 1)) : envs_per_group;
-    m.lane = threadIdx.x;            // thread in its workgroup (= lane for W == 1)
+    m.lane = lane;                   // thread in its workgroup (= lane for W == 1; tiled workgroups pass their lane)
     int g;
     if (NT) {
         g = m.lane / (NT ? NT : 1);
@@ -259,7 +262,8 @@ __device__ __forceinline__ LaneMap lane_map_from(uint32_t E, int n_agents, int e
     m.g = m.active ? g : 0;
     m.nslots = EXT ? nslots : N;
     m.nlearn = N;
-    m.rbase = m.active ? g * m.nslots : 0;  // idle lanes still execute the LDS scan: keep it in bounds
+    m.rbase = (m.active ? g * m.nslots : 0) + (int)tile * kWave;  // idle lanes still execute the LDS scan: keep it in bounds
+    m.obs0 = (int)tile * (kWave * UAVX_OBS_DIM);
     m.a0 = e0 * N;
     m.a = m.a0 + m.lane;            // whole envs are packed from thread 0: slot = a0 + thread
     m.cnt = (int)envs_here * N;
@@ -314,6 +318,17 @@ __device__ __forceinline__ bool group_any(bool v) {   // same answer in every th
     return __syncthreads_or(v ? 1 : 0) != 0;
 }
 using Lds = LdsT<false>;
+// T one-wavefront TILES side by side in one workgroup (step_kernel / step_ex_kernel, T > 1): tile t owns rows [64 t, 64 t + 64)
+// of each array -- the tile offset rides in the lane map's row base and obs0, so no LDS address needs a register of its own --
+// and orders its traffic at wavefront level like a one-wavefront workgroup (kW = 1).
+template <int T>
+struct LdsTiles {
+    static constexpr int kW = 1;
+    static constexpr int kRows = kWave * T;
+    float4 pos[kRows];
+    float theta[kRows];
+    float obs[kWave * T * UAVX_OBS_DIM];
+};
 
 // World limits of this lane's env: kernel arguments, or (EXT) the level its flags word names -- two 16-byte loads from a
 // table every lane of the chip shares, i.e. an L1/L2 hit whose latency hides under the kinematics.
@@ -645,7 +660,7 @@ template <int NT, class LDS>
 __device__ __forceinline__ void store_obs_block(const MultiParams &p, const LaneMap &m, LDS &lds, const float o[10],
                                                 float *obs_out) {
     constexpr int T = kWave * LDS::kW;
-    float *stage = lds.obs;
+    float *stage = lds.obs + m.obs0;
     if (m.active) {
         float2 *dst = reinterpret_cast<float2 *>(stage + m.lane * UAVX_OBS_DIM);
 #pragma unroll
@@ -853,17 +868,25 @@ __device__ __forceinline__ void load_action(const void *__restrict__ actions, ui
 #ifndef UAVX_STEPB
 #define UAVX_STEPB 8
 #endif
-template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void step_kernel(
+// T > 1: T independent one-wavefront tiles per workgroup (own LDS slice, wavefront-level ordering only) -- fewer workgroups for
+// the dispatcher to place.  Pays only where one-wavefront workgroups fill every slot exactly once and live short (65 536 x 8:
+// the 2.3 us over which 8 192 workgroups are placed is a large share of a 6 us wavefront); see tiles_for().
+template <int NT, bool ACT64, bool EXT, int W, int T = 1>
+__global__ __launch_bounds__(kWave * W * T, (EXT && W == 1) ? UAVX_STEPB : 1) void step_kernel(
     const void *__restrict__ actions, char *slab, uint32_t off_vel, uint32_t off_goal, uint32_t off_rec, uint32_t off_wsteps,
     uint32_t num_envs, uint32_t n_agents, uint32_t envs_per_group, uint32_t magic, uint32_t nslots, MultiParams p, int evaluate,
     float *__restrict__ obs_out, float *__restrict__ rew_out, uint8_t *__restrict__ done_out) {
-    using LDS = LdsT<EXT, W>;
+    static_assert(T == 1 || W == 1, "tiles are one-wavefront workgroups side by side");
+    using LDS = std::conditional_t<(T > 1), LdsTiles<T>, LdsT<EXT, W>>;
+    static_assert(T == 1 || !EXT, "tiles: the plain variants only");
     __shared__ LDS lds;
+    const uint32_t tile = T > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)) : 0u;   // (a scalar)
     float2 *const pos_b = reinterpret_cast<float2 *>(slab);
     double2 *const vel_b = reinterpret_cast<double2 *>(slab + off_vel);
     Goal *const goal_b = reinterpret_cast<Goal *>(slab + off_goal);
-    const LaneMap m = lane_map_from<NT, EXT, W>(num_envs, (int)n_agents, (int)envs_per_group, (int)magic, (int)nslots, blockIdx.x);
+    const uint32_t wave_id = blockIdx.x * T + tile;
+    const LaneMap m = lane_map_from<NT, EXT, W>(num_envs, (int)n_agents, (int)envs_per_group, (int)magic, (int)nslots, wave_id,
+                                                T > 1 ? threadIdx.x % kWave : threadIdx.x, tile);
     AgentRegs s = {};
     double ax = 0.0, ay = 0.0;
     uint4 rec = make_uint4(0, 0, 0, 0);
@@ -875,7 +898,7 @@ __global__ __launch_bounds__(kWave * W, (EXT && W == 1) ? UAVX_STEPB : 1) void s
         const uint32_t el = m.active ? m.e : 0u, al = m.active ? m.a : 0u;
         if (EXT) {  // the bodies' waypoint schedule runs on the env's step count and episode index
             rec = reinterpret_cast<const uint4 *>(slab + off_rec)[el];
-            wave_count = reinterpret_cast<const uint32_t *>(slab + off_wsteps)[blockIdx.x];
+            wave_count = reinterpret_cast<const uint32_t *>(slab + off_wsteps)[wave_id];
         }
         load_action<ACT64>(actions, al, ax, ay);
         const float2 d = pos_b[al];
@@ -1506,8 +1529,8 @@ __device__ __forceinline__ void stage_ahead(const P &p, const X &x, LDS &lds, ui
 #ifndef UAVX_EX8B
 #define UAVX_EX8B 8    // the 8-UAV specialisation: 65 536 x 8 is exactly 8 wavefronts per SIMD
 #endif
-template <int NT, bool ACT64, bool EXT, int W>
-__global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 8 ? UAVX_EX8B : 1))) void step_ex_kernel(const void *__restrict__ actions, char *slab, uint32_t off_vel, uint32_t off_goal,
+template <int NT, bool ACT64, bool EXT, int W, int T = 1>   // T: one-wavefront tiles per workgroup (see step_kernel)
+__global__ __launch_bounds__(kWave * W * T, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 8 ? UAVX_EX8B : 1))) void step_ex_kernel(const void *__restrict__ actions, char *slab, uint32_t off_vel, uint32_t off_goal,
                                                             uint32_t off_rec, uint32_t off_wsteps, uint32_t num_envs, uint32_t stage_first,
                                                             uint32_t pf_blocks, uint32_t step_first, uint32_t shape_packed, uint32_t magic,
                                                             MultiParams p, StepExtra x, int evaluate,
@@ -1520,8 +1543,11 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
     // (uavx_create checks they fit) instead of five pointers; the END of the kernel stores through the same registers, so the
     // register-tight variants no longer fetch those pointers a second time.
     static_assert(kExLead == 2 * sizeof(void *) + 10 * sizeof(uint32_t), "leading scalar arguments of step_ex_kernel");
-    using LDS = LdsT<EXT, W>;
+    static_assert(T == 1 || W == 1, "tiles are one-wavefront workgroups side by side");
+    using LDS = std::conditional_t<(T > 1), LdsTiles<T>, LdsT<EXT, W>>;
+    static_assert(T == 1 || !EXT, "tiles: the plain variants only");
     __shared__ LDS lds;
+    const uint32_t tile = T > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)) : 0u;   // (a scalar)
     const int N = NT ? NT : (int)(shape_packed & 0xFFu);
     float2 *const pos_b = reinterpret_cast<float2 *>(slab);
     double2 *const vel_b = reinterpret_cast<double2 *>(slab + off_vel);
@@ -1540,6 +1566,7 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
         // behind them (uavx_step_ex picks; one unsigned compare serves both)
         const uint32_t sb = blockIdx.x - stage_first;
         if (sb < pf_blocks) {   // uniform per workgroup
+            if (T > 1 && tile != 0u) return;   // a staging workgroup is ONE wavefront of work: the other tiles leave
             // The staging path reads its arguments through the laundered segment pointer: left to itself the compiler hoists
             // THOSE scalar loads in front of this branch, into the prologue of every step wavefront, and with 80 SGPRs parks
             // them in VGPR lanes there (20 v_writelane at the top of step_ex_kernel<8>).
@@ -1562,7 +1589,9 @@ __global__ __launch_bounds__(kWave * W, (W != 1) ? 1 : (EXT ? UAVX_EXB : (NT == 
     }
     // (everything the mapping needs arrived in registers with the wavefront)
     const LaneMap m = lane_map_from<NT, EXT, W>(num_envs, N, (int)((shape_packed >> 8) & 0xFFu), (int)magic,
-                                                (int)(shape_packed >> 16), blockIdx.x - step_first);
+                                                (int)(shape_packed >> 16),
+                                                (blockIdx.x - step_first) * T + tile,
+                                                T > 1 ? threadIdx.x % kWave : threadIdx.x, tile);
 #ifdef UAVX_STAMPS
     unsigned long long stamps[7] = {};
     STAMP(0);
@@ -2063,6 +2092,7 @@ struct uavx_handle {
     void *wide_slab = nullptr;
     // configs[4] extension: scripted bodies and / or an installed curriculum select the EXT kernel variants
     int gw = 1;  // wavefronts per workgroup of the step / reset / observe launches (pick_group_waves)
+    int tiles = 1;  // one-wavefront tiles per workgroup of the step launches (tiles_for)
     // layouts drawn ahead (stage_ahead): every auto-resetting uavx_step_ex launch carries ceil(G / prefetch_every) staging
     // workgroups beside its G env-workgroups
     int prefetch_every = 16;   // 0: off
@@ -2177,6 +2207,18 @@ struct StepLaunch {
         const dim3 blk(kWave * W);
         char *slab = static_cast<char *>(h->slab);
         const MultiParams &q = h->p;
+        if constexpr (NT == 8 && !EXT && W == 1) {
+            if (K == 1 && h->tiles == 2) {   // pairs of one-wavefront tiles (tiles_for)
+                const dim3 g2(grid.x / 2), b2(kWave * 2);
+                if (action_dtype == UAVX_F64)
+                    hipLaunchKernelGGL((step_kernel<NT, true, EXT, W, 2>), g2, b2, 0, st, actions, slab, h->off_vel, h->off_goal, h->off_rec, h->off_wsteps,
+                                       (uint32_t)q.E, (uint32_t)q.N, (uint32_t)q.epw, (uint32_t)q.magic, (uint32_t)q.nslots, q, evaluate, obs, rew, done);
+                else
+                    hipLaunchKernelGGL((step_kernel<NT, false, EXT, W, 2>), g2, b2, 0, st, actions, slab, h->off_vel, h->off_goal, h->off_rec, h->off_wsteps,
+                                       (uint32_t)q.E, (uint32_t)q.N, (uint32_t)q.epw, (uint32_t)q.magic, (uint32_t)q.nslots, q, evaluate, obs, rew, done);
+                return;
+            }
+        }
         if (K == 1) {
             if (action_dtype == UAVX_F64)
                 hipLaunchKernelGGL((step_kernel<NT, true, EXT, W>), grid, blk, 0, st, actions, slab, h->off_vel, h->off_goal, h->off_rec, h->off_wsteps,
@@ -2200,6 +2242,18 @@ struct StepExLaunch {
         char *slab = static_cast<char *>(h->slab);
         const uint32_t ov = h->off_vel, og = h->off_goal, orc = h->off_rec, ow = h->off_wsteps, ne = (uint32_t)h->p.E;
         const uint32_t shape = (uint32_t)h->p.N | ((uint32_t)h->p.epw << 8) | ((uint32_t)h->p.nslots << 16);   // each <= 192
+        if constexpr (NT == 8 && !EXT && W == 1) {
+            if (h->tiles == 2) {   // grid / stage_first / step_first were laid out in 128-thread workgroups by uavx_step_ex
+                const dim3 b2(kWave * 2);
+                if (a->action_dtype == UAVX_F64)
+                    hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W, 2>), grid, b2, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first,
+                                       x.pf_blocks, x.step_first, shape, (uint32_t)h->p.magic, h->p, x, a->evaluate, a->obs, a->rew, a->done);
+                else
+                    hipLaunchKernelGGL((step_ex_kernel<NT, false, EXT, W, 2>), grid, b2, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first,
+                                       x.pf_blocks, x.step_first, shape, (uint32_t)h->p.magic, h->p, x, a->evaluate, a->obs, a->rew, a->done);
+                return;
+            }
+        }
         if (a->action_dtype == UAVX_F64)
             hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W>), grid, blk, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first, x.pf_blocks,
                                x.step_first, shape, (uint32_t)h->p.magic, h->p, x, a->evaluate, a->obs, a->rew, a->done);
@@ -2493,6 +2547,18 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
             hipDeviceGetAttribute(&tpc, hipDeviceAttributeMaxThreadsPerMultiProcessor, device) == hipSuccess && cus > 0 && tpc >= kWave)
             h->wave_slots = cus * (tpc / kWave);
     }
+    {
+        // Pairs of one-wavefront tiles per workgroup (the 8-UAV specialisation only): measured in one session (r03_ab_notes.md,
+        // r04_ab_notes.md section 11), they pay where the launch fills the wavefront slots ONCE -- 65 536 x 8: 8 192 workgroups
+        // take the dispatcher 2.3 us to place, half as many 1.2 -- and cost a few percent where it runs in two rounds or leaves
+        // half the slots free (the pairs then land unevenly on the SIMDs of an issue-bound launch).
+        const long waves = (long)wave_grid(h).x;
+        h->tiles = (N == 8 && !h->ext && h->gw == 1 && waves % 2 == 0 && 2 * waves > (long)h->wave_slots && waves <= (long)h->wave_slots) ? 2 : 1;
+        if (const char *tv = getenv("UAVX_TILES")) {   // A/B switch
+            const int t = atoi(tv);
+            if (t == 1 || (t == 2 && N == 8 && !h->ext && h->gw == 1 && waves % 2 == 0)) h->tiles = t;
+        }
+    }
     p.magic_s = 65536 / (N + B) + 1;
     p.world_version = 1;
     hipLaunchKernelGGL(upload_levels_kernel, dim3(1), dim3(64), 0, 0, h->levels_dev, h->levels);  // level 0 = the config
@@ -2737,10 +2803,11 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.pf_blocks = 0; x.pf_groups = grid.x;
     x.stage_first = 0; x.step_first = 0;
     x.hints = h->hints;
-    dim3 launch = grid;
+    const unsigned step_blocks = grid.x / (unsigned)h->tiles;   // env-workgroups of the launch (tiles_for: pairs divide evenly)
+    dim3 launch(step_blocks);
     if (x.use_stage) {
         x.pf_blocks = (grid.x + (unsigned)h->prefetch_every - 1u) / (unsigned)h->prefetch_every;
-        launch.x = grid.x + x.pf_blocks;
+        launch.x = step_blocks + x.pf_blocks;
         // Where in the launch?  Workgroups are dispatched in block order.  While the env-workgroups leave wavefront slots free
         // (65 536 x 4: 4 096 of 8 192) the staging workgroups go IN FRONT and run beside them.  When the env-workgroups alone fill
         // every slot (65 536 x 8, with or without bodies: exactly 8 192 one-wavefront workgroups), whatever comes on top waits
@@ -2752,7 +2819,7 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
         // levels 22.3 / 21.8, 8 UAVs 13.8 / 13.5; 4 UAVs 7.03 / 7.02, half-full and multi-round launches within 1 %.  Workgroups
         // of several wavefronts (24 UAVs: 42 / 53 us) stay in front: their chain runs on __syncthreads and is long.
         const bool behind = h->stage_behind < 0 ? (h->gw == 1 && (long)grid.x + (long)x.pf_blocks > (long)h->wave_slots) : h->stage_behind != 0;
-        if (behind) x.stage_first = grid.x; else x.step_first = x.pf_blocks;
+        if (behind) x.stage_first = step_blocks; else x.step_first = x.pf_blocks;
     }
     dispatch(h, StepExLaunch{h, launch, st, x, a});
     UAVX_HIP(h, hipGetLastError());

@@ -53,11 +53,14 @@ def test_polar_conversion_matches_the_trainers_formula(amd, oracle_mod):
 
 @pytest.mark.parametrize("policy,code,cap,n", [("agent0_done", 1, 0, 4), ("all_done", 2, 90, 4), (None, 0, 40, 8),
                                                  ("agent0_done", 1, 55, 5), ("all_done", 2, 70, 1), ("agent0_done", 1, 1, 4),
-                                                 ("agent0_done", 1, 3, 24), ("noprefetch", 1, 30, 4)])
-def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, policy, code, cap, n):
+                                                 ("agent0_done", 1, 3, 24), ("noprefetch", 1, 30, 4), ("tiles", 1, 40, 8)])
+def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, monkeypatch, policy, code, cap, n):
     import torch
     E = 1536
     kw = dict(x_size=26.0, y_size=26.0, num_agents=n, d_sense=9.0)
+    if policy == "tiles":   # two one-wavefront tiles per workgroup (what uavx_create picks at 65 536 x 8), forced at this size
+        monkeypatch.setenv("UAVX_TILES", "2")
+        policy = "agent0_done"
     env = amd.BatchedMultiUAVWorld2D(E, seed=77, env_offset=5, **kw)
     if policy == "noprefetch":   # every reset drawn inside the step launch (the pre-drawn layouts switched off)
         env.set_prefetch(0)
@@ -316,6 +319,37 @@ def test_vector_env_surface_drives_one_launch_per_step(amd, oracle_mod):
         ended += int(info["reset_mask"].sum().item())
     assert r.shape == (512,) and d.dtype == torch.bool and ended >= 512
     sv.close()
+
+
+@pytest.mark.parametrize("E", [1536, 65536])
+def test_tile_pairs_equal_one_wavefront_workgroups(amd, monkeypatch, E):
+    """8 UAVs: a launch that fills the wavefront slots once runs two one-wavefront tiles per workgroup (tiles_for in
+    uavx_create; UAVX_TILES forces either).  Same results bit for bit, bare and fused, staging workgroups included."""
+    import torch
+    n = 8
+    if E < 65536: monkeypatch.setenv("UAVX_TILES", "2")    # (65 536 x 8 picks the pairs by itself)
+    a = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=9)
+    monkeypatch.setenv("UAVX_TILES", "1")
+    b = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=9)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for t in range(24):
+        act = (torch.rand((E, n, 2), generator=g) * 20 - 10).to(a.device)
+        if t % 3 == 0:
+            ra, rb = a.step(act), b.step(act)
+        else:
+            ra = a.step_ex(act, auto_reset="agent0_done", step_cap=7, track_returns=True)
+            rb = b.step_ex(act, auto_reset="agent0_done", step_cap=7, track_returns=True)
+            for k in ("reset_mask", "ended", "truncated"):
+                assert torch.equal(ra[3][k], rb[3][k]), (t, k)
+        for x, y in zip(ra[:3], rb[:3]):
+            assert torch.equal(x, y), t
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for k, v in a.episode_stats().items():
+        assert torch.equal(v, b.episode_stats()[k]), k
+    a.close(); b.close()
 
 
 def test_step_ex_defaults_equal_plain_step(amd):

@@ -492,14 +492,18 @@ def test_hot_kernels_keep_their_scalars_in_registers():
     for name, r in rows.items():
         if name.startswith(("step_kernel", "step_ex_kernel", "observe_kernel", "uw_step")):
             assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
-    for name in ("step_kernel<1, false, false, 1>", "step_kernel<2, false, false, 1>", "step_kernel<4, false, false, 1>",
-                 "step_kernel<8, false, false, 1>", "step_ex_kernel<4, false, false, 1>", "uw_step_kernel<false>"):
+    for name in ("step_kernel<1, false, false, 1, 1>", "step_kernel<2, false, false, 1, 1>", "step_kernel<4, false, false, 1, 1>",
+                 "step_kernel<8, false, false, 1, 1>", "step_ex_kernel<4, false, false, 1, 1>", "uw_step_kernel<false>"):
         assert rows[name]["sgpr_spill_count"] == 0, (name, rows[name])
-    for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<8, false, false, 1>"):
+    for name in ("step_kernel<0, false, true, 1, 1>", "step_ex_kernel<8, false, false, 1, 1>"):
         assert rows[name]["sgpr_spill_count"] <= 8, (name, rows[name])
+    # (two tiles per workgroup, what 65 536 x 8 runs: the tile offset rides in the row base, no register of its own)
+    assert rows["step_kernel<8, false, false, 1, 2>"]["sgpr_spill_count"] == 0
+    assert rows["step_ex_kernel<8, false, false, 1, 2>"]["sgpr_spill_count"] <= 10
     # (the fused kernel with bodies: a dozen since its leading arguments are preloaded -- and 2 % faster with them, notes section 10)
-    assert rows["step_ex_kernel<0, false, true, 1>"]["sgpr_spill_count"] <= 14, rows["step_ex_kernel<0, false, true, 1>"]
-    for name in ("step_kernel<0, false, true, 1>", "step_ex_kernel<0, false, true, 1>", "step_kernel<8, false, false, 1>",
-                 "step_ex_kernel<8, false, false, 1>", "step_kernel<4, false, false, 1>"):
+    assert rows["step_ex_kernel<0, false, true, 1, 1>"]["sgpr_spill_count"] <= 14, rows["step_ex_kernel<0, false, true, 1, 1>"]
+    for name in ("step_kernel<0, false, true, 1, 1>", "step_ex_kernel<0, false, true, 1, 1>", "step_kernel<8, false, false, 1, 1>",
+                 "step_ex_kernel<8, false, false, 1, 1>", "step_kernel<4, false, false, 1, 1>",
+                 "step_kernel<8, false, false, 1, 2>", "step_ex_kernel<8, false, false, 1, 2>"):
         r = rows[name]
         assert r["waves_per_simd"] == 8 and r["vgpr_count"] <= 64 and r["sgpr_count"] <= 80, (name, r)

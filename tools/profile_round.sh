@@ -26,6 +26,7 @@ for arg in "$@"; do
     d=$OUT/calib; rm -rf $d; mkdir -p $d
     for p in fetch write tcc_ea tcc_hit; do
       rocprofv3 --output-format csv --kernel-trace --pmc ${PASS[$p]} -d $d/$p -o run -- tools/micro/fetch_calib > $d/$p.log 2>&1
+      find $d/$p -name "*kernel_trace.csv" -delete; find $d/$p -name "*agent_info.csv" -delete   # (gpurun copies back at most 64 MiB)
       echo "calib $p done"
     done
     continue
