@@ -8,10 +8,12 @@ the process-global `np.random` stream in the same order (MUW:126-153), so a seed
 same start/target layout as with the reference; the layout is then uploaded with uavx_set_state.
 """
 import colorsys
+import os
 
 import numpy as np
 import torch
 
+from .. import _lib
 from ..batched import BatchedMultiUAVWorld2D
 from ..spaces import Box
 from .uav_agent import UAVAgentView
@@ -67,6 +69,12 @@ class MultiUAVWorld2D:
         self._act_host = torch.zeros((1, n, 2), dtype=torch.float64).pin_memory()
         self._act_np = self._act_host.numpy()
         self._act_d = torch.zeros((1, n, 2), dtype=torch.float64, device=dev)
+        # Mapped host memory: pinned (hipHostMalloc) buffers are addressable by the GPU at their host address, so the launch can
+        # read the commands from and write obs | rew | done to the pinned blocks directly -- a step is then ONE launch and a
+        # stream synchronize, no copy calls (UAVX_FACADE_COPIES=1 keeps the H2D / D2H copies, for A/B; tools/facade_rate.py).
+        self._mapped = os.environ.get("UAVX_FACADE_COPIES") != "1"
+        hp = self._host.data_ptr()
+        self._io_ptrs = (self._act_host.data_ptr(), hp, hp + n * 40, hp + n * 44)
 
     # -- counters live on the device (MUW:166-168,209,221,238) ----------------------------------------
     def _counter(self, k):
@@ -133,15 +141,21 @@ class MultiUAVWorld2D:
             raise IndexError(f"n_action must hold {n} actions of 2 components")
         for i in range(n):
             self._act_np[0, i] = n_action[i]        # float32 or float64 commands widen exactly
-        self._act_d.copy_(self._act_host, non_blocking=True)
-        self._batched.step(self._act_d, evaluate=evaluate, out=(self._obs_d, self._rew_d, self._done_d))
-        self._host.copy_(self._pack, non_blocking=True)
-        torch.cuda.current_stream(self._batched.device).synchronize()
+        b = self._batched
+        if self._mapped:
+            a, o, r, d = self._io_ptrs
+            rc = b._L.uavx_step(b._h, a, _lib.F64, 1 if evaluate else 0, o, r, d, b._stream())
+            if rc:
+                _lib.check(rc, b._h)
+        else:
+            self._act_d.copy_(self._act_host, non_blocking=True)
+            b.step(self._act_d, evaluate=evaluate, out=(self._obs_d, self._rew_d, self._done_d))
+            self._host.copy_(self._pack, non_blocking=True)
+        torch.cuda.current_stream(b.device).synchronize()   # (hipStreamSynchronize on the raw stream measured no faster)
         h = self._host_np
         obs = h[: n * 40].view(np.float32).reshape(n, 10).astype(np.float64)   # MUW:98-109 returns float64 arrays
-        rew = h[n * 40: n * 44].view(np.float32)
-        done = h[n * 44: n * 45]
-        return ([obs[i].copy() for i in range(n)], [float(r) for r in rew], [bool(d) for d in done], self._get_info())
+        # N row views of this step's fresh array, Python floats (float32 widened exactly) and bools, as MUW:241 returns them
+        return (list(obs), h[n * 40: n * 44].view(np.float32).tolist(), h[n * 44: n * 45].view(np.bool_).tolist(), self._get_info())
 
     def render(self, mode="human"):
         """MUW:243-331.  mode="human" is a no-op (no display / pygame on a compute node, and the trainers call

@@ -1,6 +1,8 @@
 """Drop-in single-env façade of UAVWorld2D (UW:11) over the batched HIP path (E = 1); drives
 run.py:6-16 and test_sac.py-style loops unchanged.  reset() draws location, velocity and target
 from np.random in the reference's order (UW:121-126)."""
+import os
+
 import numpy as np
 import torch
 
@@ -39,6 +41,13 @@ class UAVWorld2D:
         self._act_host = {np.dtype(np.float32): torch.zeros((1, 2), dtype=torch.float32).pin_memory(),
                           np.dtype(np.float64): torch.zeros((1, 2), dtype=torch.float64).pin_memory()}
         self._act_dev = {k: torch.zeros_like(v, device=dev) for k, v in self._act_host.items()}
+        # Mapped host memory (see MultiUAVWorld2D): the launch reads the command from and writes its outputs to the pinned
+        # blocks themselves; UAVX_FACADE_COPIES=1 keeps the copies (A/B).
+        self._mapped = os.environ.get("UAVX_FACADE_COPIES") != "1"
+        hp = self._host.data_ptr()
+        self._io_ptrs = (hp, hp + 16, hp + 24, hp + 20)     # obs | reward | done | distance, as in self._out
+        self._act_code = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64}
+        self._act_ptr = {k: v.data_ptr() for k, v in self._act_host.items()}
 
     @property
     def steps(self):
@@ -65,11 +74,17 @@ class UAVWorld2D:
         a = np.asarray(action)
         key = np.dtype(np.float32) if a.dtype == np.float32 else np.dtype(np.float64)  # float32 matters on step 1 (UW:142)
         self._act_host[key].numpy()[0] = a
-        self._act_dev[key].copy_(self._act_host[key], non_blocking=True)
         b = self._batched
-        b.step(self._act_dev[key], out=self._out)        # the launch writes straight into the packed block
-        self._host.copy_(self._pack, non_blocking=True)
-        torch.cuda.current_stream(b.device).synchronize()
+        if self._mapped:
+            o, r, d, i = self._io_ptrs
+            rc = b._L.uavx_uw_step(b._h, self._act_ptr[key], self._act_code[key], o, r, d, i, b._stream())
+            if rc:
+                _lib.check(rc, b._h, uw=True)
+        else:
+            self._act_dev[key].copy_(self._act_host[key], non_blocking=True)
+            b.step(self._act_dev[key], out=self._out)        # the launch writes straight into the packed block
+            self._host.copy_(self._pack, non_blocking=True)
+        torch.cuda.current_stream(b.device).synchronize()   # (hipStreamSynchronize on the raw stream measured no faster)
         h = self._host_np
         return (h[:16].view(np.float32).astype(np.float64), np.float32(h[16:20].view(np.float32)[0]), bool(h[24]),
                 {"distance": np.float32(h[20:24].view(np.float32)[0])})

@@ -12,7 +12,11 @@
  *   - all buffer arguments are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr())
  *     on the device the handle was created on; the library never allocates on the step path and
  *     never synchronises: work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
- *     null stream) and is complete when that stream reaches it.
+ *     null stream) and is complete when that stream reaches it.  The command and output buffers of a step may
+ *     also be PINNED HOST memory (hipHostMalloc, a pinned torch tensor: mapped into the device's address space at
+ *     the same address): the kernels then read / write it over the host link and the outputs are visible to the
+ *     host once the stream has been synchronised -- what the single-env facades do for their ~100-byte steps
+ *     (one launch, no copy calls); a batch belongs in HBM.
  *   - a handle is not thread-safe; use one handle per device / per caller thread.
  *   - E = number of envs, N = agents per env, agent slot a = e*N + i (agent index fastest).
  */

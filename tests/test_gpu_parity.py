@@ -629,6 +629,38 @@ def test_facade_uw_matches_reference_stream(amd):
     env.close()
 
 
+def test_facade_mapped_host_buffers_equal_the_copy_path(amd, monkeypatch):
+    """The single-env façades hand the launch their PINNED host blocks (commands in, obs | reward | done out: mapped host memory,
+    no copy calls); UAVX_FACADE_COPIES=1 keeps the H2D / D2H copies.  Same values either way, float64-position episodes too."""
+    from gym_uav_collision_avoidance_amd.envs import MultiUAVWorld2D, UAVWorld2D
+    envs = []
+    for copies in ("0", "1"):
+        monkeypatch.setenv("UAVX_FACADE_COPIES", copies)
+        envs.append((MultiUAVWorld2D(num_agents=5), UAVWorld2D()))
+    (ma, ua), (mb, ub) = envs
+    assert ma._mapped and ua._mapped and not mb._mapped and not ub._mapped
+    rng = np.random.default_rng(5)
+    for circular in (False, True):
+        outs = []
+        for m in (ma, mb):
+            np.random.seed(11)
+            outs.append(m.reset(circular=circular))
+        assert all((x == y).all() for x, y in zip(*outs))
+        for t in range(40):
+            act = [rng.uniform(-8, 8, size=2) for _ in range(5)]
+            ra, rb = ma.step(act), mb.step(act)
+            assert all((x == y).all() for x, y in zip(ra[0], rb[0])) and ra[1] == rb[1] and ra[2] == rb[2], (circular, t)
+    for u in (ua, ub):
+        np.random.seed(3)
+        u.reset()
+    for t in range(60):
+        act = rng.uniform(-10, 10, size=2).astype(np.float32 if t % 2 else np.float64)
+        ra, rb = ua.step(act), ub.step(act)
+        assert (ra[0] == rb[0]).all() and ra[1] == rb[1] and ra[2] == rb[2] and ra[3] == rb[3], t
+    for e in (ma, mb, ua, ub):
+        e.close()
+
+
 def test_hand_written_sqrt_is_ieee_on_every_float(amd):
     """uavx_selftest: the kernels' 9-instruction square root equals the compiler's correctly rounded sqrtf on all
     float32 bit patterns (0 ... +inf and a block of NaNs) on this device."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[0]: the LITERAL drop-in -- one env object stepped from a Python loop the way run.py:6-16, run_multi.py:5-23 and
-the trainers (test_sac_multi.py:99) do -- through the single-env façades (H2D of the commands + one launch + one D2H + a stream
-sync per step).  Writes profiles/rNN_facade.json: env-steps/s of UAVWorld2D and MultiUAVWorld2D(num_agents = 1, 4, 5, 8) beside the
+the trainers (test_sac_multi.py:99) do -- through the single-env façades (one launch on the façade's pinned host buffers + a stream
+sync per step; UAVX_FACADE_COPIES=1: H2D + launch + D2H instead).  Writes profiles/rNN_facade.json: env-steps/s of UAVWorld2D and MultiUAVWorld2D(num_agents = 1, 4, 5, 8) beside the
 reference's own rate on one core (profiles/*_reference_cpu.json, taken in the build container by tools/time_reference.py; the
 reference cannot run on the GPU box), with the host CPU named.  Same loop as the reference timing: polar U(-1,1)^2 commands
 (test_sac_multi.py:77-80), reset on done[0] or 1500 steps, no render.
@@ -88,8 +88,10 @@ def main():
             r["ratio_to_reference"] = r["env_steps_per_s"] / r["reference_env_steps_per_s"]
     out = dict(rows=rows, host_cpu_model=cpu_model(), host_cpus=os.cpu_count(), gpu=torch.cuda.get_device_name(0),
                python=sys.version.split()[0], numpy=np.__version__, torch=torch.__version__, seconds_per_row=SECONDS, reference=ref_meta,
-               what="one env per Python call through the drop-in façades: per step one pinned H2D copy of the commands, one step launch, "
-                    "one D2H copy of (obs | reward | done) and a stream synchronize; the Python of the loop itself (command draw, list "
+               transfer="copies" if os.environ.get("UAVX_FACADE_COPIES") == "1" else "mapped pinned host buffers",
+               what="one env per Python call through the drop-in façades: per step ONE step launch that reads the commands from and writes "
+                    "(obs | reward | done) to pinned host memory, and a stream synchronize (transfer == 'copies': a pinned H2D copy, the "
+                    "launch, a D2H copy instead); the Python of the loop itself (command draw, list "
                     "building) is inside the rate, as it is in the reference's number",
                note="a façade step is bound by launch-to-done latency (bench.py latency_us) plus two small copies and the Python around "
                     "them, not by the kernel: the batched surface (BatchedMultiUAVWorld2D / UAVVectorEnv) is what the GPU path is for; "
