@@ -2277,11 +2277,22 @@ struct ResetLaunch {
     }
 };
 
-// Wavefronts per workgroup for the runtime-N path: the smallest W in 1..4 whose workgroup of 64 W threads holds whole
-// envs with the fewest idle lanes, if that beats one wavefront by more than 10 % (N = 24: 48 of 64 lanes busy with
-// W = 1, 192 of 192 with W = 3; N = 5: 60 of 64 -> stays 1).
+// Wavefronts per workgroup for the runtime-N path.
+// Measured (one box, bare step at 1.57 M agent slots, W = 1 / 2 / 3 / 4, profiles/r04_ab_notes.md section 12): a workgroup
+// whose envs fill 64 W lanes EXACTLY (N = 3, 6, 12, 24, 48 with W = 3: every array of the workgroup's block starts and ends
+// on a 64-byte sector and the obs / velocity tiles leave as whole 16-byte rows) gains 9-19 %; nearly-full pairs gain 7-10 % at
+// N = 9, 10, 15, 20 and 37 % at N = 40; three wavefronts also at N = 7 and 11 (+9-10 %).  Five- and seven-wavefront
+// workgroups (exact for N = 5, 10 / 7, 14) LOSE 8-30 %: their envs' ordering points are workgroup barriers over too many
+// wavefronts.  Agent counts outside the table: the smallest W in 1..4 with the fewest idle lanes, if that beats one wavefront
+// by more than 10 % (a workgroup barrier replaces the wavefront-local ordering: not for a few percent).
 int pick_group_waves(int N) {
     if (N == 1 || N == 2 || N == 4 || N == 8) return 1;
+    switch (N) {
+        case 3: case 6: case 7: case 11: case 12: case 24: case 48: return 3;
+        case 9: case 10: case 15: case 20: case 40: return 2;
+        case 5: case 13: case 14: case 16: case 28: case 32: case 64: return 1;
+        default: break;
+    }
     const double u1 = (double)((kWave / N) * N) / kWave;
     double best = u1;
     int w = 1;
@@ -2289,7 +2300,7 @@ int pick_group_waves(int N) {
         const double u = (double)((kWave * c / N) * N) / (kWave * c);
         if (u > best + 1e-9) { best = u; w = c; }
     }
-    return best > 1.10 * u1 ? w : 1;   // a workgroup barrier replaces the wavefront-local ordering: not for a few percent
+    return best > 1.10 * u1 ? w : 1;
 }
 
 // float32 forms of a float64 bound b, exact for every float32 x:  (double)x >= b <=> x >= f32_at_or_above(b),
@@ -2462,6 +2473,10 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     p.N = N;
     p.B = B; p.nslots = N + B; p.kb = (B + N - 1) / N;
     h->gw = B > 0 ? 1 : pick_group_waves(N);
+    if (const char *gv = getenv("UAVX_GW")) {   // A/B switch: wavefronts per workgroup of the runtime-N kernels
+        const int w = atoi(gv);
+        if (w >= 1 && w <= 4 && B == 0 && !(N == 1 || N == 2 || N == 4 || N == 8)) h->gw = w;
+    }
     p.epw = std::min(kWave * h->gw / N, kExtSlots / (N + B));  // an EXT wave keeps epw * (L + B) neighbour rows in LDS
     p.magic = 65536 / N + 1;
     p.E = num_envs;
@@ -2959,7 +2974,7 @@ struct SnapHeader {
     uint64_t slab_bytes, wide_bytes;
     int64_t E, env_offset;
     int32_t N, B, wide, ext, n_levels, level_lo, level_hi, prefetch_every;
-    uint32_t world_version, pad;
+    uint32_t world_version, epw;   // epw: envs per workgroup -- what the per-workgroup step counters of the slab are indexed by
     uavx_config cfg;
     uavx_body_rule rule;
     LevelTable levels;
@@ -2990,7 +3005,7 @@ int uavx_save(uavx_handle *h, void *dst, void *stream) {
     hd.slab_bytes = h->slab_bytes; hd.wide_bytes = h->wide ? wide_slab_bytes(h) : 0;
     hd.E = h->p.E; hd.env_offset = h->p.env_offset; hd.N = h->p.N; hd.B = h->p.B; hd.wide = h->wide ? 1 : 0; hd.ext = h->ext ? 1 : 0;
     hd.n_levels = h->p.n_levels; hd.level_lo = h->p.level_lo; hd.level_hi = h->p.level_hi; hd.prefetch_every = h->prefetch_every;
-    hd.world_version = h->p.world_version;
+    hd.world_version = h->p.world_version; hd.epw = (uint32_t)h->p.epw;
     hd.cfg = h->cfg; hd.rule = h->rule; hd.levels = h->levels;
     char *b = static_cast<char *>(dst);
     hipLaunchKernelGGL(snap_header_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<SnapHeader *>(b), hd);   // (by value: no host buffer to keep alive)
@@ -3009,8 +3024,8 @@ int uavx_load(uavx_handle *h, const void *src, void *stream) {
     UAVX_HIP(h, hipStreamSynchronize(st));   // the header decides what follows: this call waits for `stream`
     if (hd.magic != kSnapMagic || hd.version != UAVX_VERSION || hd.header_bytes != snap_header_bytes())
         return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: not a snapshot of this library version");
-    if (hd.E != h->p.E || hd.N != h->p.N || hd.B != h->p.B || hd.slab_bytes != h->slab_bytes)
-        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: the snapshot was taken from a handle of another shape (envs / agents / bodies)");
+    if (hd.E != h->p.E || hd.N != h->p.N || hd.B != h->p.B || hd.slab_bytes != h->slab_bytes || hd.epw != (uint32_t)h->p.epw)
+        return fail(h, UAVX_ERR_INVALID_ARG, "uavx_load: the snapshot was taken from a handle of another shape (envs / agents / bodies / envs per workgroup)");
     // everything else the header carries goes into copy lengths, kernel arguments and table indices: a truncated or damaged
     // snapshot is refused here, not found out by a kernel
     const bool lvl_ok = hd.n_levels >= 0 && hd.n_levels <= UAVX_MAX_LEVELS &&

@@ -214,7 +214,8 @@ def test_snapshot_restores_a_running_batch_exactly(amd, n, bodies, tmp_path):
     import struct
     for off, fmt, bad in ((24, "<Q", 1 << 40),      # wide_bytes: would be the length of a device-to-device copy
                           (64, "<i", 99),           # n_levels: indexes the level table
-                          (76, "<i", -5)):          # prefetch_every
+                          (76, "<i", -5),           # prefetch_every
+                          (84, "<I", 7)):           # envs per workgroup: what the per-workgroup step counters are indexed by
         broken = sd["snapshot"].clone()
         broken[off:off + struct.calcsize(fmt)] = torch.tensor(list(struct.pack(fmt, bad)), dtype=torch.uint8, device=broken.device)
         with pytest.raises(ValueError):
