@@ -8,7 +8,7 @@ D=tools/ab/asan
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 if [ "$1" = build ]; then
   mkdir -p $D
-  F="-O1 -g -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -fPIC -Wall -Wno-unused-function"
+  F="-O1 -g -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=14 -fPIC -Wall -Wno-unused-function"
   hipcc $F -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer -shared -shared-libsan \
         -o $D/libuavx.so gym_uav_collision_avoidance_amd/csrc/uavx_multi.hip gym_uav_collision_avoidance_amd/csrc/uavx_uw.hip
   python3 -c "import oracle; print(oracle.build())" > /dev/null
@@ -21,6 +21,8 @@ else
   export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
   LD_PRELOAD=$RT $D/abi_client 512 4 200
   LD_PRELOAD=$RT $D/abi_client 96 9 120
+  LD_PRELOAD=$RT $D/abi_client 96 12 250                      # three wavefronts per workgroup (pick_group_waves)
+  UAVX_TILES=2 LD_PRELOAD=$RT $D/abi_client 512 8 100         # two one-wavefront tiles per workgroup
   LD_PRELOAD=$RT $D/abi_client_ext 256 8 16 120
   LD_PRELOAD=$RT $D/abi_client_ext 64 24 0 60
   echo "asan host pass done"
