@@ -53,7 +53,8 @@ def test_polar_conversion_matches_the_trainers_formula(amd, oracle_mod):
 
 @pytest.mark.parametrize("policy,code,cap,n", [("agent0_done", 1, 0, 4), ("all_done", 2, 90, 4), (None, 0, 40, 8),
                                                  ("agent0_done", 1, 55, 5), ("all_done", 2, 70, 1), ("agent0_done", 1, 1, 4),
-                                                 ("agent0_done", 1, 3, 24), ("noprefetch", 1, 30, 4), ("tiles", 1, 40, 8)])
+                                                 ("agent0_done", 1, 3, 24), ("noprefetch", 1, 30, 4), ("tiles", 1, 40, 8),
+                                                 ("all_done", 2, 45, 10), ("agent0_done", 1, 30, 12)])
 def test_auto_reset_and_episode_stats_vs_oracle(amd, oracle_mod, monkeypatch, policy, code, cap, n):
     import torch
     E = 1536

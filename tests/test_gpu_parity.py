@@ -221,7 +221,9 @@ def test_float64_position_mode_vs_oracle_and_back(amd, oracle_mod, n, E):
 
 
 # (1, 4096) is BASELINE configs[1] literally: 4 096 parallel envs x 1 UAV
-N_CASES = [(1, 4096), (2, 2048), (3, 1000), (4, 4096), (5, 777), (8, 1024), (16, 256), (24, 130), (33, 64), (64, 70)]
+# (3, 6, 7, 11, 12, 24 run three wavefronts per workgroup, 9, 10, 15, 20 two: pick_group_waves' measured table)
+N_CASES = [(1, 4096), (2, 2048), (3, 1000), (4, 4096), (5, 777), (6, 700), (7, 500), (8, 1024), (10, 400), (11, 300), (12, 300),
+           (15, 200), (16, 256), (20, 150), (24, 130), (33, 64), (64, 70)]
 
 
 @pytest.mark.parametrize("n,E", N_CASES)
