@@ -72,7 +72,7 @@ class MultiUAVWorld2D:
         # Mapped host memory: pinned (hipHostMalloc) buffers are addressable by the GPU at their host address, so the launch can
         # read the commands from and write obs | rew | done to the pinned blocks directly -- a step is then ONE launch and a
         # stream synchronize, no copy calls (UAVX_FACADE_COPIES=1 keeps the H2D / D2H copies, for A/B; tools/facade_rate.py).
-        self._mapped = os.environ.get("UAVX_FACADE_COPIES") != "1"
+        self._mapped = os.environ.get("UAVX_FACADE_COPIES") != "1" and self._host.is_pinned()   # (only page-locked memory is mapped)
         hp = self._host.data_ptr()
         self._io_ptrs = (self._act_host.data_ptr(), hp, hp + n * 40, hp + n * 44)
 

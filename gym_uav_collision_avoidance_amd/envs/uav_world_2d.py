@@ -43,7 +43,7 @@ class UAVWorld2D:
         self._act_dev = {k: torch.zeros_like(v, device=dev) for k, v in self._act_host.items()}
         # Mapped host memory (see MultiUAVWorld2D): the launch reads the command from and writes its outputs to the pinned
         # blocks themselves; UAVX_FACADE_COPIES=1 keeps the copies (A/B).
-        self._mapped = os.environ.get("UAVX_FACADE_COPIES") != "1"
+        self._mapped = os.environ.get("UAVX_FACADE_COPIES") != "1" and self._host.is_pinned()   # (only page-locked memory is mapped)
         hp = self._host.data_ptr()
         self._io_ptrs = (hp, hp + 16, hp + 24, hp + 20)     # obs | reward | done | distance, as in self._out
         self._act_code = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64}
