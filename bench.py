@@ -325,7 +325,7 @@ def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60)
     del ring, env
     torch.cuda.empty_cache()
     shape = f"{E}x{N}" + (f"+{bodies}" if bodies else "")
-    nt = N if (N in (1, 2, 4, 8) and not bodies) else 0
+    nt = N if (N in (1, 2, 4, 5, 8) and not bodies) else 0
     traffic = measured_traffic(f"uavx::step_kernel<{nt}", shape)
     return dict(bound="hbm", achieved=b / kernel_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b / kernel_s / 1e9 / HBM_PEAK_GBS,
                 traffic=traffic[0] if traffic else None, traffic_source=traffic[1] if traffic else None,
@@ -361,7 +361,7 @@ def open_loop_point(E, N, device, gen, K=32, reps=40):
     torch.cuda.empty_cache()
     res = {"K": K, "tape_out": True, "us_per_step": us, "value": E / us * 1e6, "unit": "env-steps/s",
            "note": "uavx_step_k: K steps per launch from an action tape, all outputs of every step written; informational"}
-    rv = valu_roofline(f"uavx::step_kernel<{N if N in (1, 2, 4, 8) else 0}", f"{E}x{N}", us * 1e-6)
+    rv = valu_roofline(f"uavx::step_kernel<{N if N in (1, 2, 4, 5, 8) else 0}", f"{E}x{N}", us * 1e-6)
     if rv is not None:   # same step body: the single-step kernel's instruction count per wavefront stands for it
         res["valu_frac"] = rv["frac"]
     return res
@@ -583,7 +583,7 @@ def main():
 
     E, N, B, K, W = args.envs, args.agents, args.bodies, args.steps, args.warmup
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    nt = lambda n: n if n in (1, 2, 4, 8) else 0
+    nt = lambda n: n if n in (1, 2, 4, 5, 8) else 0
     ext = False
     if args.world == "uw":
         N, B = 1, 0

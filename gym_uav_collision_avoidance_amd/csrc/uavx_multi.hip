@@ -477,7 +477,7 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
 template <int NT, bool STEP, class LDS>
 __device__ __forceinline__ Neigh scan_neighbours(float sq_sense, const LaneMap &m, const LDS &lds, float nx,
                                                  float ny) {
-    if (NT != 0 && NT <= 4) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);
+    if (NT != 0 && NT <= 5) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);
     const int N = NT ? NT : m.nslots;
     if (NT == 0 && N <= 5) return scan_neighbours_exact<NT, STEP>(sq_sense, m, lds, nx, ny);  // <= 4 others: nothing to save
     const float4 *row = &lds.pos[m.rbase];
@@ -2172,7 +2172,7 @@ float sq_limit_le(float lim) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Kernel variant of a handle: compile-time agent count NT (1, 2, 4, 8; 0 = runtime N), EXT (scripted bodies / curriculum),
+// Kernel variant of a handle: compile-time agent count NT (1, 2, 4, 5, 8; 0 = runtime N), EXT (scripted bodies / curriculum),
 // W wavefronts per workgroup (runtime-N path only).  dispatch() calls l.run<NT, EXT, W>() for the handle's variant.
 template <class L>
 void dispatch(const uavx_handle *h, const L &l) {
@@ -2188,6 +2188,7 @@ void dispatch(const uavx_handle *h, const L &l) {
         case 1: return l.template run<1, false, 1>();
         case 2: return l.template run<2, false, 1>();
         case 4: return l.template run<4, false, 1>();
+        case 5: return l.template run<5, false, 1>();   // (run_multi.py:5, test_pytorch_multi.py:27)
         case 8: return l.template run<8, false, 1>();
         default: break;
     }
@@ -2286,11 +2287,11 @@ struct ResetLaunch {
 // wavefronts.  Agent counts outside the table: the smallest W in 1..4 with the fewest idle lanes, if that beats one wavefront
 // by more than 10 % (a workgroup barrier replaces the wavefront-local ordering: not for a few percent).
 int pick_group_waves(int N) {
-    if (N == 1 || N == 2 || N == 4 || N == 8) return 1;
+    if (N == 1 || N == 2 || N == 4 || N == 5 || N == 8) return 1;   // compile-time specialisations: one wavefront
     switch (N) {
         case 3: case 6: case 7: case 11: case 12: case 24: case 48: return 3;
         case 9: case 10: case 15: case 20: case 40: return 2;
-        case 5: case 13: case 14: case 16: case 28: case 32: case 64: return 1;
+        case 13: case 14: case 16: case 28: case 32: case 64: return 1;
         default: break;
     }
     const double u1 = (double)((kWave / N) * N) / kWave;
@@ -2475,7 +2476,7 @@ int uavx_create(const uavx_config *cfg, int64_t num_envs, int64_t env_offset, in
     h->gw = B > 0 ? 1 : pick_group_waves(N);
     if (const char *gv = getenv("UAVX_GW")) {   // A/B switch: wavefronts per workgroup of the runtime-N kernels
         const int w = atoi(gv);
-        if (w >= 1 && w <= 4 && B == 0 && !(N == 1 || N == 2 || N == 4 || N == 8)) h->gw = w;
+        if (w >= 1 && w <= 4 && B == 0 && !(N == 1 || N == 2 || N == 4 || N == 5 || N == 8)) h->gw = w;
     }
     p.epw = std::min(kWave * h->gw / N, kExtSlots / (N + B));  // an EXT wave keeps epw * (L + B) neighbour rows in LDS
     p.magic = 65536 / N + 1;
