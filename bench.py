@@ -306,6 +306,32 @@ def single_step_latency(step, ring, device, trials=200):
     return statistics.median(lat)
 
 
+def reset_observe_point(env, N, bodies, device, reps=30):
+    """The other two launches of the path (MUW:116-175 reset, MUW:60-109 _get_obs) on the bench's own batch: a full-batch
+    uavx_reset (Philox draw + accept / reject chain of every env) and uavx_observe, device time per launch over HIP events.
+    Informational: an RL loop resets inside step_ex (--fused) and reads observations from the step launch."""
+    E = env.num_envs
+    out = {}
+    for name, fn, per_agent, per_env in (("reset", lambda: env.reset(), 8 + 16 + 16 + 40, 16 + 16 + 24 * bodies),
+                                         ("observe", lambda: env.observe(), 8 + 16 + 16 + 40, 16 * bodies)):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        us = a.elapsed_time(b) * 1e3 / reps
+        nbytes = (per_agent * N + per_env) * E
+        out[name] = {"us_per_launch": us, "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / us / 1e3,
+                     "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBS}
+    out["note"] = ("full-batch uavx_reset (written: 40 B of state + the 40 B observation per agent, the env record; the time is Philox + "
+                   "the accept / reject chain, not bytes) and uavx_observe (40 B read + 40 B written per agent); eager launches back to back, HIP events")
+    return out
+
+
 def large_batch_point(N, device, gen, bodies=0, E=1 << 20, steps=300, warmup=60):
     """The same step kernel on a batch whose working set (state + double-buffered outputs + action ring, ~0.9 GB at
     N=4) is several times the 256 MiB Infinity Cache, i.e. a launch that really streams from HBM."""
@@ -777,7 +803,7 @@ def main():
                                            "per_rank_ms_per_step: each rank's own median region"}
         if world > 1:
             line["omitted_for_n_gpus>1"] = ["cpu_baseline", "speedup_vs_cpu_baseline", "roofline_steady", "roofline_large", "latency_us",
-                                            "open_loop_step_k", "split_batch"]
+                                            "open_loop_step_k", "split_batch", "reset_observe"]
         if args.world == "multi":
             rv = valu_roofline(kernel_name, shape, kernel_s)
             if rv is not None:
@@ -803,6 +829,12 @@ def main():
             line["latency_us"] = {"single_step_launch_to_done": single_step_latency(step, ring, device),
                                   "kernel": kernel_s * 1e6,
                                   "note": "one step from an idle stream, host-visible; small batches are bound by this, not by bytes"}
+        if world == 1 and args.world == "multi" and not args.fused:
+            try:   # an extra measurement must never cost the line
+                line["reset_observe"] = reset_observe_point(env, N, B, device)
+            except Exception as exc:
+                print(f"[bench] reset_observe skipped ({type(exc).__name__}: {exc})", file=sys.stderr)
+                torch.cuda.synchronize(device)
         if world == 1 and not args.no_large and args.world == "multi" and not args.fused and E < (1 << 20):
             env.close()
             del ring

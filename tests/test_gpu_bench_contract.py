@@ -38,6 +38,8 @@ def test_single_gpu_line():
     assert d["ms_per_step"] == pytest.approx(sorted(d["repeat_ms_per_step"])[2])          # the median region
     assert d["config"]["mode"] == "graph" and d["config"]["graph_replays"] == 6            # 300 = 6 x 50-step graphs
     assert "L3-resident" in r["note"] and d["gather_ms"] > 0 and d["latency_us"]["single_step_launch_to_done"] > 0
+    ro = d["reset_observe"]               # the path's other two launches on the same batch (informational)
+    assert 0 < ro["observe"]["us_per_launch"] < ro["reset"]["us_per_launch"] < 1e3
     sp = d["split_batch"]                 # the same batch as two independent half-batch chains (informational, not `value`)
     assert sp["chains"] == 2 and sp["envs"] == 65536 and sp["value"] > 0.8 * d["value"] and 0.3 < sp["frac"] < 1.0
     big = d["roofline_large"]
