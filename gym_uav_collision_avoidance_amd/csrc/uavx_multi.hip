@@ -2200,6 +2200,9 @@ void dispatch(const uavx_handle *h, const L &l) {
     }
 }
 
+// Tiles per workgroup of THIS launch: the handle's choice (uavx_create) as long as it runs the plain 8-UAV kernels.
+inline int launch_tiles(const uavx_handle *h) { return (h->tiles == 2 && !h->ext && h->p.N == 8 && h->gw == 1) ? 2 : 1; }
+
 struct StepLaunch {
     uavx_handle *h; dim3 grid; hipStream_t st;
     const void *actions; int action_dtype, evaluate, K, tape_out;
@@ -2209,7 +2212,7 @@ struct StepLaunch {
         char *slab = static_cast<char *>(h->slab);
         const MultiParams &q = h->p;
         if constexpr (NT == 8 && !EXT && W == 1) {
-            if (K == 1 && h->tiles == 2) {   // pairs of one-wavefront tiles (tiles_for)
+            if (K == 1 && launch_tiles(h) == 2) {   // pairs of one-wavefront tiles (uavx_create)
                 const dim3 g2(grid.x / 2), b2(kWave * 2);
                 if (action_dtype == UAVX_F64)
                     hipLaunchKernelGGL((step_kernel<NT, true, EXT, W, 2>), g2, b2, 0, st, actions, slab, h->off_vel, h->off_goal, h->off_rec, h->off_wsteps,
@@ -2244,7 +2247,7 @@ struct StepExLaunch {
         const uint32_t ov = h->off_vel, og = h->off_goal, orc = h->off_rec, ow = h->off_wsteps, ne = (uint32_t)h->p.E;
         const uint32_t shape = (uint32_t)h->p.N | ((uint32_t)h->p.epw << 8) | ((uint32_t)h->p.nslots << 16);   // each <= 192
         if constexpr (NT == 8 && !EXT && W == 1) {
-            if (h->tiles == 2) {   // grid / stage_first / step_first were laid out in 128-thread workgroups by uavx_step_ex
+            if (launch_tiles(h) == 2) {   // grid / stage_first / step_first were laid out in 128-thread workgroups by uavx_step_ex
                 const dim3 b2(kWave * 2);
                 if (a->action_dtype == UAVX_F64)
                     hipLaunchKernelGGL((step_ex_kernel<NT, true, EXT, W, 2>), grid, b2, 0, st, a->actions, slab, ov, og, orc, ow, ne, x.stage_first,
@@ -2819,7 +2822,9 @@ int uavx_step_ex(uavx_handle *h, const uavx_step_args *a, void *stream) {
     x.pf_blocks = 0; x.pf_groups = grid.x;
     x.stage_first = 0; x.step_first = 0;
     x.hints = h->hints;
-    const unsigned step_blocks = grid.x / (unsigned)h->tiles;   // env-workgroups of the launch (tiles_for: pairs divide evenly)
+    // env-workgroups of the launch: pairs of tiles divide evenly (uavx_create); a handle that has since been given a curriculum
+    // runs the kernels with levels, which keep one tile per workgroup
+    const unsigned step_blocks = grid.x / (unsigned)launch_tiles(h);
     dim3 launch(step_blocks);
     if (x.use_stage) {
         x.pf_blocks = (grid.x + (unsigned)h->prefetch_every - 1u) / (unsigned)h->prefetch_every;

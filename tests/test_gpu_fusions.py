@@ -351,6 +351,26 @@ def test_tile_pairs_equal_one_wavefront_workgroups(amd, monkeypatch, E):
         assert torch.equal(sa[k], sb[k]), k
     for k, v in a.episode_stats().items():
         assert torch.equal(v, b.episode_stats()[k]), k
+    # a curriculum installed later moves the handle to the kernels with levels, which keep ONE tile per workgroup: the launch
+    # must be laid out for those from then on (every env stepped, same results as the handle that never had the pairs)
+    levels = [dict(x_size=40.0, y_size=40.0, collider_radius=1.0, d_sense=12.0, n_active=6),
+              dict(x_size=55.0, y_size=50.0, collider_radius=1.0, d_sense=16.0)]
+    for env in (a, b):
+        env.set_curriculum(levels, lo=0, hi=1)
+    oa, ob = a.reset(seed=5), b.reset(seed=5)
+    assert torch.equal(oa, ob)
+    for t in range(12):
+        act = (torch.rand((E, n, 2), generator=g) * 20 - 10).to(a.device)
+        ra = a.step_ex(act, auto_reset="agent0_done", step_cap=5, track_returns=True)
+        rb = b.step_ex(act, auto_reset="agent0_done", step_cap=5, track_returns=True)
+        for x, y in zip(ra[:3], rb[:3]):
+            assert torch.equal(x, y), ("levels", t)
+        assert torch.equal(ra[3]["reset_mask"], rb[3]["reset_mask"])
+        seen = ra[3]["reset_mask"].clone() if t == 0 else seen | ra[3]["reset_mask"]
+    assert bool(seen.all())                                # the cap re-initialised EVERY env: none was left out of a launch
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
     a.close(); b.close()
 
 
