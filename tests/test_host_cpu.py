@@ -167,11 +167,12 @@ def test_gloo_world2_evaluation_summary_over_an_odd_total():
     assert got["avg_score"] == pytest.approx((rows * 0.5).sum() / (4 * total))
 
 
-def test_gloo_world2_metrics_gather():
+@pytest.mark.parametrize("world,total", [(2, 11), (8, 37)])   # uneven shards: 6 + 5; 5 x 5 + 3 x 4 (the node's eight ranks)
+def test_gloo_metrics_gather(world, total):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port, total, world = _free_port(), 11, 2   # uneven shards: 6 + 5
+    port = _free_port()
     procs = [ctx.Process(target=_gather_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
