@@ -128,16 +128,34 @@ def test_gpus_2_without_a_launcher():
     _check_two_ranks(d2)
 
 
-def _check_two_ranks(d):
-    """The N > 1 line proves what it ran on: two ranks seen by the process group, a time per rank, the same HSA environment in
+def test_gpus_4_without_a_launcher():
+    """Four self-launched ranks (rehearsal: they share the one GPU, gloo): the line the scaling curve's N = 4 point would print --
+    262 144 envs in all is BASELINE configs[3]'s total, tagged from what ran."""
+    env = dict(os.environ, UAVX_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["envs_per_gpu"] == 65536 and d["config"]["parallelism"] == "env-index shard x4"
+    assert abs(d["value"] - 4 * 65536 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+    assert "configs[3]" in d["config"]["workload"] and "65 536 envs PER GPU" in out.stderr
+    _check_two_ranks(d, 4)
+
+
+def _check_two_ranks(d, n=2):
+    """The N > 1 line proves what it ran on: n ranks seen by the process group, a time per rank, the same HSA environment in
     both launch forms (an outer torchrun and bench.py's own launcher)."""
     g = d["distributed"]
-    assert g["ranks_seen"] == 2 and g["backend"] == "gloo" and g["rehearsal_shared_gpu"] is True
-    assert len(g["per_rank"]) == 2 and [r["rank"] for r in g["per_rank"]] == [0, 1]
-    assert len(g["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in g["per_rank_ms_per_step"])
+    assert g["ranks_seen"] == n and g["backend"] == "gloo" and g["rehearsal_shared_gpu"] is True
+    assert len(g["per_rank"]) == n and [r["rank"] for r in g["per_rank"]] == list(range(n))
+    assert len(g["per_rank_ms_per_step"]) == n and all(t > 0 for t in g["per_rank_ms_per_step"])
     assert d["ms_per_step"] >= 0.999 * min(g["per_rank_ms_per_step"])     # the line's time is the slowest rank's, region by region
     assert {r["hsa_enable_ipc_mode_legacy"] for r in g["per_rank"]} == {d["hsa_env"]["HSA_ENABLE_IPC_MODE_LEGACY"]} == {"0"}
-    assert len({r["pid"] for r in g["per_rank"]}) == 2
+    assert len({r["pid"] for r in g["per_rank"]}) == n
 
 
 def test_rccl_code_path_with_one_rank():
