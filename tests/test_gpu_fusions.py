@@ -323,7 +323,7 @@ def test_vector_env_surface_drives_one_launch_per_step(amd, oracle_mod):
     sv.close()
 
 
-@pytest.mark.parametrize("E", [1536, 65536])
+@pytest.mark.parametrize("E", [1536, 1531, 65536])    # (1 531: the last tile of the last workgroup holds three envs of eight)
 def test_tile_pairs_equal_one_wavefront_workgroups(amd, monkeypatch, E):
     """8 UAVs: a launch that fills the wavefront slots once runs two one-wavefront tiles per workgroup (tiles_for in
     uavx_create; UAVX_TILES forces either).  Same results bit for bit, bare and fused, staging workgroups included."""
