@@ -2286,9 +2286,8 @@ struct ResetLaunch {
 // whose envs fill 64 W lanes EXACTLY (N = 3, 6, 12, 24, 48 with W = 3: every array of the workgroup's block starts and ends
 // on a 64-byte sector and the obs / velocity tiles leave as whole 16-byte rows) gains 9-19 %; nearly-full pairs gain 7-10 % at
 // N = 9, 10, 15, 20 and 37 % at N = 40; three wavefronts also at N = 7 and 11 (+9-10 %).  Five- and seven-wavefront
-// workgroups (exact for N = 5, 10 / 7, 14) LOSE 8-30 %: their envs' ordering points are workgroup barriers over too many
-// wavefronts.  Agent counts outside the table: the smallest W in 1..4 with the fewest idle lanes, if that beats one wavefront
-// by more than 10 % (a workgroup barrier replaces the wavefront-local ordering: not for a few percent).
+// workgroups (exact for N = 5, 10 / 7, 14) LOSE 8-30 % (not through their barriers: removing two of the three changed nothing).  Agent counts outside the table: the smallest W in 1..4 with the fewest idle lanes, if that beats one wavefront
+// by more than 10 % (wider workgroups cost 0-2 % at W = 2 / 3 and 7-13 % at W = 4 where one wavefront is already aligned).
 int pick_group_waves(int N) {
     if (N == 1 || N == 2 || N == 4 || N == 5 || N == 8) return 1;   // compile-time specialisations: one wavefront
     switch (N) {
