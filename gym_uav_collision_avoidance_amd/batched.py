@@ -633,6 +633,13 @@ class BatchedUAVWorld2D(_Base):
             self._dones = [torch.zeros((E,), dtype=torch.uint8, device=self.device) for _ in range(2)]
             self._infos = [torch.zeros((E,), dtype=torch.float32, device=self.device) for _ in range(2)]
         self._flip = 0
+        # what an eager loop would otherwise rebuild on every call (the host cost of a call is what bounds small batches)
+        self._act_shape = torch.Size((E, 2))
+        self._ptrs = [(self._obs[f].data_ptr(), self._rews[f].data_ptr(), self._dones[f].data_ptr(), self._infos[f].data_ptr())
+                      for f in range(2)]
+        self._done_bools = [d.view(torch.bool) for d in self._dones]
+        self._step_infos = [{"distance": self._infos[f]} for f in range(2)]
+        self._step_fn = self._L.uavx_uw_step
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -666,6 +673,15 @@ class BatchedUAVWorld2D(_Base):
     def step(self, actions, out=None):  # UW:137-173
         """out = (obs [E,4] f32, rew [E] f32, done [E] u8 / bool, distance [E] f32): caller-owned device buffers the launch
         writes into (the single-env façade packs them into one block so that a step is one launch and ONE copy back)."""
+        if (out is None and type(actions) is torch.Tensor and actions.shape == self._act_shape and actions.dtype in _TORCH_DT
+                and actions.is_contiguous() and actions.device == self.device):
+            self._flip ^= 1  # fast path: a device tensor of the right shape, internal output buffers
+            f = self._flip
+            o, r, d, i = self._ptrs[f]
+            rc = self._step_fn(self._h, actions.data_ptr(), _TORCH_DT[actions.dtype], o, r, d, i, self._stream())
+            if rc:
+                _lib.check(rc, self._h, uw=True)
+            return self._obs[f], self._rews[f], self._done_bools[f], self._step_infos[f]
         a, code = self._actions_arg(actions, (self.num_envs, 2))
         if out is None:
             obs = self._next_obs_buf()
@@ -685,19 +701,32 @@ class BatchedUAVWorld2D(_Base):
         converts policy outputs a in [-1,1]^2 (v = (a0/2+0.5)*action_space.high[0], theta = a1*pi); auto_reset
         re-initialises an env in the call AFTER the one that returned done (info["reset_mask"]); episode returns
         and lengths are accumulated per env (episode_stats())."""
-        a, code = self._actions_arg(actions, (self.num_envs, 2))
-        obs = self._next_obs_buf()
+        if (type(actions) is torch.Tensor and actions.shape == self._act_shape and actions.dtype in _TORCH_DT
+                and actions.is_contiguous() and actions.device == self.device):
+            a, code = actions, _TORCH_DT[actions.dtype]
+        else:
+            a, code = self._actions_arg(actions, (self.num_envs, 2))
         if not hasattr(self, "_reset_mask"):
             self._reset_mask = torch.zeros((3, self.num_envs), dtype=torch.uint8, device=self.device)
-        m = self._reset_mask
-        rew, done, info = self._rews[self._flip], self._dones[self._flip], self._infos[self._flip]
-        args = _lib.UWStepArgs(a.data_ptr(), code, _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN,
-                               int(bool(auto_reset)), int(step_cap), int(bool(track_returns)), 0, self.seed,
-                               obs.data_ptr(), rew.data_ptr(), done.data_ptr(), info.data_ptr(),
-                               m[0].data_ptr(), m[1].data_ptr(), m[2].data_ptr())
-        _lib.check(self._L.uavx_uw_step_ex(self._h, ctypes.byref(args), self._stream()), self._h, uw=True)
-        mb = m.view(torch.bool)
-        return obs, rew, done.view(torch.bool), {"distance": info, "reset_mask": mb[0], "ended": mb[1], "truncated": mb[2]}
+            mb = self._reset_mask.view(torch.bool)
+            self._ex_args = [None, None]
+            for f in range(2):   # one argument struct per output buffer set, reused: only what changes is written per call
+                o, r, d, i = self._ptrs[f]
+                self._ex_args[f] = _lib.UWStepArgs(0, 0, 0, 0, 0, 0, 0, 0, o, r, d, i, self._reset_mask[0].data_ptr(),
+                                                   self._reset_mask[1].data_ptr(), self._reset_mask[2].data_ptr())
+            self._ex_refs = [ctypes.byref(x) for x in self._ex_args]
+            self._ex_infos = [{"distance": self._infos[f], "reset_mask": mb[0], "ended": mb[1], "truncated": mb[2]} for f in range(2)]
+            self._ex_fn = self._L.uavx_uw_step_ex
+        self._flip ^= 1
+        f = self._flip
+        args = self._ex_args[f]
+        args.actions, args.action_dtype = a.data_ptr(), code
+        args.action_mode = _lib.ACTION_POLAR if polar else _lib.ACTION_CARTESIAN
+        args.auto_reset, args.step_cap, args.track_returns, args.seed = (1 if auto_reset else 0), int(step_cap), (1 if track_returns else 0), self.seed
+        rc = self._ex_fn(self._h, self._ex_refs[f], self._stream())
+        if rc:
+            _lib.check(rc, self._h, uw=True)
+        return self._obs[f], self._rews[f], self._done_bools[f], self._ex_infos[f]
 
     def episode_stats(self):
         c = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)
