@@ -374,6 +374,37 @@ def test_tile_pairs_equal_one_wavefront_workgroups(amd, monkeypatch, E):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n", [3, 10, 12])
+def test_workgroup_width_does_not_change_results(amd, monkeypatch, n):
+    """The runtime-N kernels pick their wavefronts per workgroup from a measured table (three at 3 and 12 UAVs, two at 10);
+    UAVX_GW forces one.  A launch-shape choice only: same trajectories bit for bit, bare and fused, resets included."""
+    import torch
+    E = 1000
+    a = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=4, x_size=30.0, y_size=30.0)
+    monkeypatch.setenv("UAVX_GW", "1")
+    b = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=4, x_size=30.0, y_size=30.0)
+    monkeypatch.setenv("UAVX_GW", "4")
+    c = amd.BatchedMultiUAVWorld2D(E, num_agents=n, seed=4, x_size=30.0, y_size=30.0)
+    envs = (a, b, c)
+    obs = [e.reset() for e in envs]
+    assert torch.equal(obs[0], obs[1]) and torch.equal(obs[0], obs[2])
+    g = torch.Generator(device="cpu").manual_seed(8)
+    for t in range(30):
+        act = (torch.rand((E, n, 2), generator=g) * 20 - 10).to(a.device)
+        if t % 4 == 0:
+            rs = [e.step(act) for e in envs]
+        else:
+            rs = [e.step_ex(act, auto_reset="agent0_done", step_cap=6, track_returns=True) for e in envs]
+            assert torch.equal(rs[0][3]["reset_mask"], rs[1][3]["reset_mask"]) and torch.equal(rs[0][3]["reset_mask"], rs[2][3]["reset_mask"])
+        for k in range(3):
+            assert torch.equal(rs[0][k], rs[1][k]) and torch.equal(rs[0][k], rs[2][k]), (t, k)
+    st = [e.get_state() for e in envs]
+    for k in st[0]:
+        assert torch.equal(st[0][k], st[1][k]) and torch.equal(st[0][k], st[2][k]), k
+    for e in envs:
+        e.close()
+
+
 def test_step_ex_defaults_equal_plain_step(amd):
     import torch
     E, n = 3000, 4
